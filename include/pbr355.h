@@ -1,0 +1,151 @@
+/*
+ * pbr355 — C ABI of the MI355X (gfx950) PBR frame path and IBL precompute.
+ *
+ * The reference (maoz233/wgpu-renderer) has no FFI seam: its Renderer class drives a WebGPU
+ * GPUDevice directly.  Each entry point below stands in for the WebGPU calls one reference
+ * method makes, so a host that keeps the reference's Renderer / glTFLoader / Camera / HDRLoader
+ * surface can bind this library instead of navigator.gpu.  Citations are file:line in the
+ * reference checkout.
+ *
+ * Conventions: every call returns 0 on success or a negative PBR_E_* code; pbr_last_error()
+ * gives the message.  The caller owns all host pointers; the library copies during the call.
+ * A context is bound to one HIP device and one stream; calls on one context are not re-entrant,
+ * different contexts may be driven from different threads.  Matrices are column-major f32,
+ * cube maps are [face][y][x][rgba] with faces +X,-X,+Y,-Y,+Z,-Z.
+ */
+#ifndef PBR355_H
+#define PBR355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PBR_OK 0
+#define PBR_E_ARG (-1)        /* invalid argument */
+#define PBR_E_STATE (-2)      /* a prerequisite upload / precompute is missing */
+#define PBR_E_DEVICE (-3)     /* HIP runtime error or no usable gfx950 device */
+#define PBR_E_UNSUPPORTED (-4)
+
+typedef struct PbrContext PbrContext;
+
+/* Material texture slots in the order renderer.ts:605-632 loads them. */
+enum PbrTextureSlot {
+  PBR_TEX_ALBEDO = 0,              /* rgba8unorm-srgb, renderer.ts:647 */
+  PBR_TEX_METALLIC_ROUGHNESS = 1,  /* rgba8unorm,      renderer.ts:663 */
+  PBR_TEX_NORMAL = 2,              /* rgba8unorm,      renderer.ts:681 */
+  PBR_TEX_EMISSIVE = 3,            /* rgba8unorm-srgb, renderer.ts:697 */
+  PBR_TEX_OCCLUSION = 4            /* rgba8unorm,      renderer.ts:713 */
+};
+
+/* IBL products, renderer.ts:757-779 and :978-993. */
+enum PbrIblMap {
+  PBR_MAP_SKYBOX = 0,      /* CubemapType.SKYBOX:     [6][s][s] rgba32f */
+  PBR_MAP_IRRADIANCE = 1,  /* CubemapType.IRRADIANCE: [6][s][s] rgba32f */
+  PBR_MAP_PREFILTER = 2,   /* CubemapType.PREFILTER:  mips of [6][s>>m][s>>m] rgba32f */
+  PBR_MAP_BRDF_LUT = 3,    /* generateBRDFLUT:        [s][s] rgba16f */
+  PBR_MAP_HDR = 4          /* the uploaded equirect HDR and its mip chain, rgba32f */
+};
+
+/* What drawFrame writes into its uniform buffers each frame (renderer.ts:1828-1932). */
+typedef struct PbrFrameUniforms {
+  float model[16];          /* Transform.model       shader.wgsl:15, renderer.ts:1833-1834 */
+  float normal[16];         /* Transform.normal      shader.wgsl:16, renderer.ts:1837-1838 */
+  float view[16];           /* Transform.view        shader.wgsl:17, renderer.ts:1841-1842 */
+  float projection[16];     /* Transform.projection  shader.wgsl:18, renderer.ts:1845-1853 */
+  float inv_view_proj[16];  /* skybox matrix         skybox.wgsl:7,  renderer.ts:1864-1867 */
+  float view_pos[4];        /* shader.wgsl:22, renderer.ts:1878-1884 */
+  float light_pos[4][4];    /* shader.wgsl:23, renderer.ts:1887-1894 (vec3 in 16-byte slots) */
+  float light_color[4][4];  /* shader.wgsl:24, renderer.ts:1905-1912 */
+  float emissive_factor[4]; /* shader.wgsl:28, renderer.ts:614-626 */
+  uint32_t sampler_index;   /* renderer.ts:1927-1932: 1 U repeat | 2 V repeat | 4 mag linear | 8 min linear; bit 16 (MSAA) is rejected */
+  uint32_t use_mipmaps;     /* renderer.ts:1977: material textures sampled with their mip chains */
+  uint32_t reserved[2];
+} PbrFrameUniforms;
+
+/* Per-frame timings (the reference's timestamp query, renderer.ts:1968-1974, :2040-2044) and
+ * the coverage figure the bandwidth model needs.  Filling it synchronises the stream. */
+typedef struct PbrFrameStats {
+  float ms_vertex;      /* vertex transform kernel */
+  float ms_setup;       /* triangle setup + binning kernels */
+  float ms_raster;      /* tile rasteriser */
+  float ms_resolve;     /* deferred shading resolve */
+  float ms_total;       /* first launch to last completion */
+  uint32_t covered_pixels;   /* pixels whose visibility entry is a triangle */
+  uint32_t binned_refs;      /* triangle-tile references produced by binning */
+  uint32_t setup_triangles;  /* front-facing (sub)triangles after clipping and culling */
+  uint32_t reserved;
+} PbrFrameStats;
+
+/* ---- lifetime: replaces requestAdapter/requestDevice, renderer.ts:144-198 ---- */
+int pbr_create(int device_ordinal, PbrContext** ctx_out);
+int pbr_destroy(PbrContext* ctx);
+const char* pbr_last_error(const PbrContext* ctx);   /* ctx may be NULL: error of the last failed pbr_create on this thread */
+/* Run this context's work on an existing HIP stream (hipStream_t); NULL restores the context's own. */
+int pbr_set_stream(PbrContext* ctx, void* hip_stream);
+int pbr_synchronize(PbrContext* ctx);
+
+/* ---- geometry: createVertexBuffer/createIndexBuffer, renderer.ts:504-540 ----
+ * verts: n_verts x 8 floats (pos3, uv2, normal3 — the Geometry layout of glTF.ts:186-214);
+ * indices: uint16 triangle list (glTF.ts:222-226).  instance_count>1 draws the mesh once per
+ * instance with the model / normal matrices given (each instance_count x 16 floats); with
+ * instance_count==1 both may be NULL and the frame's Transform is used, as in the reference. */
+int pbr_upload_mesh(PbrContext* ctx, const float* verts, int32_t n_verts, const uint16_t* indices, int32_t n_indices,
+                    int32_t instance_count, const float* instance_model, const float* instance_normal);
+
+/* ---- material textures: createTexture2DFromSource + copySourceToTexture, renderer.ts:1039-1101.
+ * rgba8 is the decoded image, w*h*4 bytes, top row first.  gen_mips!=0 also builds the full chain
+ * (calculateMipLevelCount, utils.ts:20-24) the way generateMipmaps does (renderer.ts:1103-1321). ---- */
+int pbr_upload_texture(PbrContext* ctx, int slot, const uint8_t* rgba8, int32_t w, int32_t h, int32_t is_srgb, int32_t gen_mips);
+
+/* ---- HDR source: the writeTexture of generateCubemap (renderer.ts:1449, :1520) plus the mip
+ * chain generateMipmaps builds for the prefilter source (renderer.ts:1537). ---- */
+int pbr_upload_hdr(PbrContext* ctx, const float* rgba32f, int32_t w, int32_t h);
+
+/* ---- IBL precompute: generateCubemap / generateBRDFLUT, renderer.ts:1323-1732 ---- */
+int pbr_ibl_equirect_to_cube(PbrContext* ctx, int32_t size);   /* CubemapType.SKYBOX, equirectangular.wgsl */
+int pbr_ibl_irradiance(PbrContext* ctx, int32_t size);         /* CubemapType.IRRADIANCE, irradiancemap.wgsl */
+/* CubemapType.PREFILTER, prefiltermap.wgsl: mips levels with roughness mip/(mips-1) (renderer.ts:1559),
+ * samples must be 1024 (SAMPLE_COUNT, prefiltermap.wgsl:3).  The texels of all mips, flattened in
+ * (mip, face, y, x) order, are cut into shard_count equal ranges and only range shard_index is
+ * computed; (0,1) computes everything. */
+int pbr_ibl_prefilter(PbrContext* ctx, int32_t size, int32_t mips, int32_t samples, int32_t shard_index, int32_t shard_count);
+int pbr_ibl_brdf_lut(PbrContext* ctx, int32_t size);           /* brdf.wgsl */
+
+/* Size in bytes and dimensions of one level of a map (level 0 for single-level maps). */
+int pbr_ibl_level_info(PbrContext* ctx, int which, int32_t level, int32_t* w, int32_t* h, int32_t* layers, size_t* bytes);
+/* Copy one level to host memory (rgba32f, or rgba16f bits for the LUT). */
+int pbr_ibl_download(PbrContext* ctx, int which, int32_t level, void* out, size_t out_bytes);
+/* Device address of a whole map (all levels back to back) for device-side exchange, e.g. an
+ * all-gather of prefilter shards; total_bytes may be NULL. */
+int pbr_ibl_device_ptr(PbrContext* ctx, int which, void** dev_ptr, size_t* total_bytes);
+/* Byte range [begin,end) of the prefilter map that shard (shard_index, shard_count) writes. */
+int pbr_ibl_prefilter_shard_range(PbrContext* ctx, int32_t shard_index, int32_t shard_count, size_t* begin, size_t* end);
+
+/* ---- the frame: drawFrame's render pass, renderer.ts:1998-2013 ----
+ * Renders rows [y0,y1) of a w x h target (y0,y1 even, or y1==h) with the helmet draw
+ * (drawIndexed, renderer.ts:2006) followed by the skybox draw (renderer.ts:2011).
+ * rgba8_out: (y1-y0)*w*4 bytes, R,G,B,A per pixel; vis_out (optional): (y1-y0)*w uint32, triangle
+ * id + 1 with instance i's triangles offset by i*n_indices/3, 0 where the skybox shows. */
+int pbr_draw_frame(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1,
+                   uint8_t* rgba8_out, uint32_t* vis_out, PbrFrameStats* stats);
+/* Same pass with outputs left in device memory (d_vis may be NULL); returns without synchronising
+ * unless stats is given. */
+int pbr_draw_frame_device(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1,
+                          void* d_rgba8, void* d_vis, PbrFrameStats* stats);
+/* Stage outputs for verification: clip[n][4], world[n][3], normal[n][3] of vs_main
+ * (shader.wgsl:37-47) for n = instance_count*n_verts, and the f32 depth buffer of the last frame. */
+int pbr_debug_vertex_stage(PbrContext* ctx, const PbrFrameUniforms* u, float* clip, float* world, float* normal);
+int pbr_debug_depth(PbrContext* ctx, float* depth_out, size_t n_floats);
+
+/* ---- kernel timing for benchmarks: HIP events recorded on the context's stream around the
+ * resolve kernel of every frame drawn while enabled. ---- */
+int pbr_profile_begin(PbrContext* ctx, int32_t max_frames);
+int pbr_profile_end(PbrContext* ctx, int32_t* frames, float* resolve_ms_total, float* raster_ms_total, float* frame_ms_total);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

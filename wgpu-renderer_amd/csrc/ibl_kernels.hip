@@ -1,0 +1,270 @@
+// gfx950 kernels for the IBL precompute: mip chains, equirect -> cube, irradiance convolution,
+// GGX prefilter and the split-sum BRDF table.  They produce what the reference's compute shaders
+// produce (src/shaders/equirectangular.wgsl, irradiancemap.wgsl, prefiltermap.wgsl, brdf.wgsl,
+// mipmap.wgsl) but are organised for 64-wide wavefronts: everything that depends only on the
+// sample index is hoisted into tables, sample loops are split across lanes and reduced with
+// cross-lane shuffles, and texel gathers are 16-byte loads.
+#include "pbr_internal.h"
+#include "devmath.h"
+
+namespace {
+
+constexpr float PI_F = 3.14159265359f;
+constexpr float INV_ATAN_X = 0.1591f, INV_ATAN_Y = 0.3183f;   // equirectangular.wgsl:2
+
+// Face bases of equirectangular.wgsl:20-57: forward, up, right.
+__constant__ float FACE_TABLE[6][9] = {
+    {1, 0, 0, 0, 1, 0, 0, 0, -1},  {-1, 0, 0, 0, 1, 0, 0, 0, 1}, {0, -1, 0, 0, 0, 1, 1, 0, 0},
+    {0, 1, 0, 0, 0, -1, 1, 0, 0},  {0, 0, 1, 0, 1, 0, 1, 0, 0},  {0, 0, -1, 0, 1, 0, -1, 0, 0},
+};
+
+// Direction of destination texel (gx, gy) of face gz; the reference applies no half-texel offset
+// (equirectangular.wgsl:60-65).
+PBR_DEV V3 texel_direction(int gx, int gy, int gz, int size) {
+  float dim = (float)size;
+  float cu = (float)gx / dim * 2.0f - 1.0f;
+  float cv = (float)gy / dim * 2.0f - 1.0f;
+  const float* f = FACE_TABLE[gz];
+  V3 d = v3(f[0] + f[6] * cu + f[3] * cv, f[1] + f[7] * cu + f[4] * cv, f[2] + f[8] * cu + f[5] * cv);
+  return normalize(d);
+}
+
+// Truncating equirect texel index of direction d in a w x h level (equirectangular.wgsl:68-69).
+PBR_DEV uint32_t equirect_index(V3 d, int w, int h) {
+  float u = atan2f(d.z, d.x) * INV_ATAN_X + 0.5f;
+  float v = asinf(fminf(fmaxf(d.y, -1.0f), 1.0f)) * INV_ATAN_Y + 0.5f;
+  int x = min(max((int)(u * (float)w), 0), w - 1);
+  int y = min(max((int)(v * (float)h), 0), h - 1);
+  return (uint32_t)y * (uint32_t)w + (uint32_t)x;
+}
+
+PBR_DEV float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
+PBR_DEV float linear_to_srgb(float c) { return c <= 0.0031308f ? c * 12.92f : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f; }
+
+// Footprint of the one bilinear tap mipmap.wgsl takes at a destination texel centre (clamp-to-edge).
+PBR_DEV void mip_axis(int dst_i, int dst_n, int src_n, int& i0, int& i1, float& a) {
+  float u = ((float)dst_i + 0.5f) / (float)dst_n;
+  float t = u * (float)src_n - 0.5f;
+  float fl = floorf(t);
+  a = t - fl;
+  int i = (int)fl;
+  i0 = min(max(i, 0), src_n - 1);
+  i1 = min(max(i + 1, 0), src_n - 1);
+}
+
+__global__ void __launch_bounds__(256) mip_rgba32f_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int sw, int sh, int dw, int dh) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dw || y >= dh) return;
+  int x0, x1, y0, y1; float a, b;
+  mip_axis(x, dw, sw, x0, x1, a);
+  mip_axis(y, dh, sh, y0, y1, b);
+  float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+  float4 t00 = src[(size_t)y0 * sw + x0], t10 = src[(size_t)y0 * sw + x1], t01 = src[(size_t)y1 * sw + x0], t11 = src[(size_t)y1 * sw + x1];
+  float4 o;
+  o.x = ((t00.x * w00 + t10.x * w10) + t01.x * w01) + t11.x * w11;
+  o.y = ((t00.y * w00 + t10.y * w10) + t01.y * w01) + t11.y * w11;
+  o.z = ((t00.z * w00 + t10.z * w10) + t01.z * w01) + t11.z * w11;
+  o.w = ((t00.w * w00 + t10.w * w10) + t01.w * w01) + t11.w * w11;
+  dst[(size_t)y * dw + x] = o;
+}
+
+__global__ void __launch_bounds__(256) mip_rgba8_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int sw, int sh, int dw, int dh, int srgb) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dw || y >= dh) return;
+  int x0, x1, y0, y1; float a, b;
+  mip_axis(x, dw, sw, x0, x1, a);
+  mip_axis(y, dh, sh, y0, y1, b);
+  float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+  uint32_t t00 = src[(size_t)y0 * sw + x0], t10 = src[(size_t)y0 * sw + x1], t01 = src[(size_t)y1 * sw + x0], t11 = src[(size_t)y1 * sw + x1];
+  uint32_t out = 0;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float s00 = (float)((t00 >> (8 * c)) & 255u) / 255.0f, s10 = (float)((t10 >> (8 * c)) & 255u) / 255.0f;
+    float s01 = (float)((t01 >> (8 * c)) & 255u) / 255.0f, s11 = (float)((t11 >> (8 * c)) & 255u) / 255.0f;
+    const bool enc = srgb && c < 3;   // the average is taken in linear light and re-encoded at every level
+    if (enc) { s00 = srgb_to_linear(s00); s10 = srgb_to_linear(s10); s01 = srgb_to_linear(s01); s11 = srgb_to_linear(s11); }
+    float v = ((s00 * w00 + s10 * w10) + s01 * w01) + s11 * w11;
+    if (enc) v = linear_to_srgb(v);
+    out |= to_unorm8(v) << (8 * c);
+  }
+  dst[(size_t)y * dw + x] = out;
+}
+
+__global__ void __launch_bounds__(256) equirect_to_cube_kernel(DevEquirect hdr, float4* __restrict__ out, int size) {
+  int gx = blockIdx.x * 64 + (threadIdx.x & 63), gy = blockIdx.y * 4 + (threadIdx.x >> 6), gz = blockIdx.z;
+  if (gx >= size || gy >= size) return;
+  V3 d = texel_direction(gx, gy, gz, size);
+  out[((size_t)gz * size + gy) * size + gx] = hdr.base[equirect_index(d, hdr.w, hdr.h)];
+}
+
+// One workgroup per output texel: thread p owns azimuth step p and walks the polar steps; the
+// partial sums are reduced across the wave by shuffles and across the four waves through LDS.
+// tables = cos(phi)[n_phi], sin(phi)[n_phi], sin(theta)[n_theta], cos(theta)[n_theta] for the angles
+// the reference's f32 loop counters take (irradiancemap.wgsl:75-76).
+__global__ void __launch_bounds__(256) irradiance_kernel(DevEquirect hdr, const float* __restrict__ tables, int n_phi, int n_theta,
+                                                         float4* __restrict__ out, int size) {
+  __shared__ float s_sin_t[128], s_cos_t[128];
+  __shared__ float s_part[4][3];
+  const int t = blockIdx.x;
+  const int gz = t / (size * size), gy = (t / size) % size, gx = t % size;
+  for (int i = threadIdx.x; i < n_theta; i += 256) { s_sin_t[i] = tables[2 * n_phi + i]; s_cos_t[i] = tables[2 * n_phi + n_theta + i]; }
+  __syncthreads();
+  V3 n = texel_direction(gx, gy, gz, size);
+  V3 right = normalize(cross(v3(0, 1, 0), n));
+  V3 up = normalize(cross(n, right));
+  float r = 0, g = 0, b = 0;
+  for (int p = threadIdx.x; p < n_phi; p += 256) {
+    const float cp = tables[p], sp = tables[n_phi + p];
+    for (int q = 0; q < n_theta; ++q) {
+      const float st = s_sin_t[q], ct = s_cos_t[q];
+      V3 sv = right * (st * cp) + up * (st * sp) + n * ct;
+      float4 tex = hdr.base[equirect_index(sv, hdr.w, hdr.h)];
+      r += tex.x * ct * st; g += tex.y * ct * st; b += tex.z * ct * st;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { r += __shfl_xor(r, o); g += __shfl_xor(g, o); b += __shfl_xor(b, o); }
+  if ((threadIdx.x & 63) == 0) { s_part[threadIdx.x >> 6][0] = r; s_part[threadIdx.x >> 6][1] = g; s_part[threadIdx.x >> 6][2] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float inv = 1.0f / (float)(n_phi * n_theta);
+    float sr = (s_part[0][0] + s_part[1][0]) + (s_part[2][0] + s_part[3][0]);
+    float sg = (s_part[0][1] + s_part[1][1]) + (s_part[2][1] + s_part[3][1]);
+    float sb = (s_part[0][2] + s_part[1][2]) + (s_part[2][2] + s_part[3][2]);
+    out[t] = make_float4(PI_F * sr * inv, PI_F * sg * inv, PI_F * sb * inv, 1.0f);
+  }
+}
+
+// GGX prefilter of one cube level.  SPLIT lanes share a texel and stride the sample table; the
+// table holds, per kept sample, the light direction in the texel's tangent frame, the two source
+// levels and their blend — all independent of the texel because N = V (prefiltermap.wgsl:124-126).
+template <int SPLIT>
+__global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples,
+                                                        float total_weight, float4* __restrict__ out, int size, long long first, long long count) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long local = gid / SPLIT;
+  const int sub = (int)(gid % SPLIT);
+  const bool live = local < count;
+  const long long t = first + (live ? local : 0);
+  const int gz = (int)(t / ((long long)size * size)), gy = (int)((t / size) % size), gx = (int)(t % size);
+  const V3 N = texel_direction(gx, gy, gz, size);
+  const V3 upv = fabsf(N.z) < 0.999f ? v3(0, 0, 1) : v3(1, 0, 0);   // prefiltermap.wgsl:56-61
+  const V3 T = normalize(cross(upv, N));
+  const V3 B = cross(N, T);
+  float r = 0, g = 0, b = 0;
+  for (int i = sub; i < n_samples; i += SPLIT) {
+    const PrefilterSample s = samples[i];
+    const V3 L = T * s.lx + B * s.ly + N * s.lz;
+    const float u = atan2f(L.z, L.x) * INV_ATAN_X + 0.5f;
+    const float v = asinf(fminf(fmaxf(L.y, -1.0f), 1.0f)) * INV_ATAN_Y + 0.5f;
+    const int w0 = max(1, hdr.w >> s.l0), h0 = max(1, hdr.h >> s.l0), w1 = max(1, hdr.w >> s.l1), h1 = max(1, hdr.h >> s.l1);
+    const int x0 = min((int)(u * (float)w0), w0 - 1), y0 = min((int)(v * (float)h0), h0 - 1);
+    const int x1 = min((int)(u * (float)w1), w1 - 1), y1 = min((int)(v * (float)h1), h1 - 1);
+    const float4 a = hdr.base[hdr.off[s.l0] + (uint32_t)max(y0, 0) * (uint32_t)w0 + (uint32_t)max(x0, 0)];
+    const float4 c = hdr.base[hdr.off[s.l1] + (uint32_t)max(y1, 0) * (uint32_t)w1 + (uint32_t)max(x1, 0)];
+    const float wa = (1.0f - s.mix) * s.lz, wc = s.mix * s.lz;
+    r += a.x * wa + c.x * wc; g += a.y * wa + c.y * wc; b += a.z * wa + c.z * wc;
+  }
+#pragma unroll
+  for (int o = SPLIT / 2; o > 0; o >>= 1) { r += __shfl_xor(r, o); g += __shfl_xor(g, o); b += __shfl_xor(b, o); }
+  if (live && sub == 0) out[t] = make_float4(r / total_weight, g / total_weight, b / total_weight, 1.0f);
+}
+
+// One workgroup covers 256 texels of one LUT row; the row's roughness fixes the half-vector table,
+// which is built once in LDS and then read as a broadcast by every lane.
+__global__ void __launch_bounds__(256) brdf_lut_kernel(uint16_t* __restrict__ out, int size) {
+  __shared__ float s_h[PBR_PREFILTER_SAMPLES][3];
+  const int y = blockIdx.y, x = blockIdx.x * 256 + threadIdx.x;
+  const float fsize = (float)size;
+  const float roughness = (fsize - (float)y) / (fsize - 1.0f);   // brdf.wgsl:104 (row 0 is above 1)
+  const float a = roughness * roughness;
+  for (int i = threadIdx.x; i < PBR_PREFILTER_SAMPLES; i += 256) {
+    const float xi_x = (float)i / (float)PBR_PREFILTER_SAMPLES;
+    const float xi_y = (float)__brev((uint32_t)i) * 2.3283064365386963e-10f;   // brdf.wgsl:9-16
+    const float phi = 2.0f * PI_F * xi_x;
+    const float ct = sqrtf((1.0f - xi_y) / (1.0f + (a * a - 1.0f) * xi_y));
+    const float st = sqrtf(1.0f - ct * ct);
+    // N = (0,0,1) makes the tangent frame tangent = (0,-1,0), bitangent = (1,0,0) (brdf.wgsl:33-43)
+    V3 h = normalize(v3(sinf(phi) * st, -(cosf(phi) * st), ct));
+    s_h[i][0] = h.x; s_h[i][1] = h.y; s_h[i][2] = h.z;
+  }
+  __syncthreads();
+  if (x >= size) return;
+  const float ndotv = (float)x / (fsize - 1.0f);
+  const V3 V = v3(sqrtf(1.0f - ndotv * ndotv), 0.0f, ndotv);
+  const float k = (roughness * roughness) / 2.0f;                 // brdf.wgsl:57-59
+  const float g_v = ndotv / (ndotv * (1.0f - k) + k);
+  float A = 0.0f, Bsum = 0.0f;
+  for (int i = 0; i < PBR_PREFILTER_SAMPLES; ++i) {
+    const V3 H = v3(s_h[i][0], s_h[i][1], s_h[i][2]);
+    const float vh = dot(V, H);
+    const V3 L = normalize(H * (2.0f * vh) - V);
+    const float ndotl = fmaxf(L.z, 0.0f), ndoth = fmaxf(H.z, 0.0f), vdoth = fmaxf(vh, 0.0f);
+    if (ndotl > 0.0f) {
+      const float g_l = ndotl / (ndotl * (1.0f - k) + k);
+      const float G = g_v * g_l;
+      const float g_vis = (G * vdoth) / (ndoth * ndotv);          // 0/0 = NaN in column 0, kept on purpose
+      const float fc = pow5(1.0f - vdoth);
+      A += (1.0f - fc) * g_vis;
+      Bsum += fc * g_vis;
+    }
+  }
+  A /= (float)PBR_PREFILTER_SAMPLES; Bsum /= (float)PBR_PREFILTER_SAMPLES;
+  ushort4 o;
+  o.x = __half_as_ushort(__float2half_rn(A));
+  o.y = __half_as_ushort(__float2half_rn(Bsum));
+  o.z = __half_as_ushort(__float2half_rn(0.0f));
+  o.w = __half_as_ushort(__float2half_rn(1.0f));
+  reinterpret_cast<ushort4*>(out)[(size_t)y * size + x] = o;
+}
+
+}  // namespace
+
+void launch_build_mips_rgba32f(hipStream_t s, float4* chain, const uint32_t* off, int w, int h, int levels) {
+  for (int l = 1; l < levels; ++l) {
+    int sw = std::max(1, w >> (l - 1)), sh = std::max(1, h >> (l - 1)), dw = std::max(1, w >> l), dh = std::max(1, h >> l);
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    hipLaunchKernelGGL(mip_rgba32f_kernel, grid, dim3(256), 0, s, chain + off[l - 1], chain + off[l], sw, sh, dw, dh);
+  }
+}
+
+void launch_build_mips_rgba8(hipStream_t s, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb) {
+  for (int l = 1; l < levels; ++l) {
+    int sw = std::max(1, w >> (l - 1)), sh = std::max(1, h >> (l - 1)), dw = std::max(1, w >> l), dh = std::max(1, h >> l);
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4);
+    hipLaunchKernelGGL(mip_rgba8_kernel, grid, dim3(256), 0, s, chain + off[l - 1], chain + off[l], sw, sh, dw, dh, srgb);
+  }
+}
+
+void launch_equirect_to_cube(hipStream_t s, DevEquirect hdr, float4* out, int size) {
+  dim3 grid((size + 63) / 64, (size + 3) / 4, 6);
+  hipLaunchKernelGGL(equirect_to_cube_kernel, grid, dim3(256), 0, s, hdr, out, size);
+}
+
+void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int n_phi, int n_theta, float4* out, int size) {
+  hipLaunchKernelGGL(irradiance_kernel, dim3(6 * size * size), dim3(256), 0, s, hdr, tables, n_phi, n_theta, out, size);
+}
+
+void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, float total_weight,
+                      float4* out_level, int level_size, int64_t first, int64_t count) {
+  if (count <= 0) return;
+  // Few texels: spread each texel's samples over a whole wave so the chip still fills.
+  if (count >= (1 << 18)) {
+    long long threads = count;
+    hipLaunchKernelGGL(prefilter_kernel<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+                       out_level, level_size, (long long)first, (long long)count);
+  } else if (count >= (1 << 14)) {
+    long long threads = count * 8;
+    hipLaunchKernelGGL(prefilter_kernel<8>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+                       out_level, level_size, (long long)first, (long long)count);
+  } else {
+    long long threads = count * 64;
+    hipLaunchKernelGGL(prefilter_kernel<64>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+                       out_level, level_size, (long long)first, (long long)count);
+  }
+}
+
+void launch_brdf_lut(hipStream_t s, uint16_t* out, int size) {
+  dim3 grid((size + 255) / 256, size);
+  hipLaunchKernelGGL(brdf_lut_kernel, grid, dim3(256), 0, s, out, size);
+}

@@ -1,0 +1,743 @@
+// Host side of libpbr355: the C ABI declared in include/pbr355.h.  Owns device memory, prepares
+// the small per-call tables on the host and enqueues the gfx950 kernels on the context's stream.
+// There is no CPU fallback: every entry point needs a HIP device.
+#include "pbr_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+int fail(PbrContext* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->error = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                      \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(ctx, PBR_E_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) { (void)hipGetDevice(&prev); if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+template <typename T>
+void free_dev(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+int level_count(int w, int h) { return (int)(1 + std::log2((double)std::max(w, h))); }   // utils.ts:20-24
+
+void chain_offsets(int w, int h, int levels, uint32_t* off, size_t* total) {
+  size_t o = 0;
+  for (int l = 0; l < PBR_MAX_LEVELS; ++l) {
+    off[l] = (uint32_t)o;
+    if (l < levels) o += (size_t)std::max(1, w >> l) * std::max(1, h >> l);
+  }
+  *total = o;
+}
+void cube_offsets(int size, int levels, uint32_t* off, size_t* total) {
+  size_t o = 0;
+  for (int l = 0; l < PBR_MAX_LEVELS; ++l) {
+    off[l] = (uint32_t)o;
+    if (l < levels) { size_t s = std::max(1, size >> l); o += 6 * s * s; }
+  }
+  *total = o;
+}
+
+// (projection * view) with the element order the vertex kernel and the parity oracle use.
+#pragma clang fp contract(off)
+void mat4_mul_host(const float* a, const float* b, float* o) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      volatile float p0 = a[r] * b[c * 4], p1 = a[4 + r] * b[c * 4 + 1], p2 = a[8 + r] * b[c * 4 + 2], p3 = a[12 + r] * b[c * 4 + 3];
+      volatile float s01 = p0 + p1;
+      volatile float s012 = s01 + p2;
+      o[c * 4 + r] = s012 + p3;
+    }
+}
+
+uint32_t radical_inverse(uint32_t bits) {
+  bits = (bits << 16) | (bits >> 16);
+  bits = ((bits & 0x55555555u) << 1) | ((bits & 0xAAAAAAAAu) >> 1);
+  bits = ((bits & 0x33333333u) << 2) | ((bits & 0xCCCCCCCCu) >> 2);
+  bits = ((bits & 0x0F0F0F0Fu) << 4) | ((bits & 0xF0F0F0F0u) >> 4);
+  bits = ((bits & 0x00FF00FFu) << 8) | ((bits & 0xFF00FF00u) >> 8);
+  return bits;
+}
+
+// Everything prefiltermap.wgsl:131-168 computes per sample that does not depend on the output
+// texel.  With N = R = V the half vector, N.L, the pdf and therefore the source mip are functions
+// of the sample index and the roughness only; they are tabulated in the texel's tangent frame
+// (tangent, bitangent, N) and samples with N.L <= 0 are dropped.
+int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out, float* total_weight) {
+  const float PI = 3.14159265359f;
+  const uint32_t N = PBR_PREFILTER_SAMPLES;
+  if (roughness == 0.0f) {
+    // every sample is H = L = N with weight 1 and source level 0: one entry reproduces the sum exactly
+    PrefilterSample s = {0.0f, 0.0f, 1.0f, 0.0f, 0, std::min(1, src_levels - 1), 0.0f, 0.0f};
+    out[0] = s;
+    *total_weight = 1.0f;
+    return 1;
+  }
+  int n = 0;
+  float total = 0.0f;
+  const float a = roughness * roughness;
+  for (uint32_t i = 0; i < N; ++i) {
+    const float xi_x = (float)i / (float)N, xi_y = (float)radical_inverse(i) * 2.3283064365386963e-10f;
+    const float phi = 2.0f * PI * xi_x;
+    const float ct = std::sqrt((1.0f - xi_y) / (1.0f + (a * a - 1.0f) * xi_y));
+    const float st = std::sqrt(1.0f - ct * ct);
+    float hx = std::cos(phi) * st, hy = std::sin(phi) * st, hz = ct;
+    const float hl = std::sqrt(hx * hx + hy * hy + hz * hz);
+    hx /= hl; hy /= hl; hz /= hl;
+    const float vdoth = hz;   // V = N = (0,0,1) in the tangent frame
+    float lx = 2.0f * vdoth * hx, ly = 2.0f * vdoth * hy, lz = 2.0f * vdoth * hz - 1.0f;
+    const float ll = std::sqrt(lx * lx + ly * ly + lz * lz);
+    lx /= ll; ly /= ll; lz /= ll;
+    const float ndotl = std::max(lz, 0.0f);
+    if (!(ndotl > 0.0f)) continue;
+    const float a2 = a * a, ndoth = std::max(hz, 0.0f), hdotv = std::max(vdoth, 0.0f);
+    float denom = ndoth * ndoth * (a2 - 1.0f) + 1.0f;
+    denom = PI * denom * denom;
+    const float D = a2 / denom;
+    const float pdf = D * ndoth / (4.0f * hdotv) + 0.0001f;
+    const float sa_texel = 4.0f * PI / (6.0f * 512.0f * 512.0f);   // prefiltermap.wgsl:143-144: 512 is hard-coded
+    const float sa_sample = 1.0f / ((float)N * pdf + 0.0001f);
+    const float mip = 0.5f * std::log2(sa_sample / sa_texel);
+    const int m0 = (int)std::floor(mip);
+    PrefilterSample s;
+    s.lx = lx; s.ly = ly; s.lz = ndotl;
+    s.mix = mip - (float)m0;
+    s.l0 = std::min(std::max(m0, 0), src_levels - 1);       // a level outside the chain is clamped into it
+    s.l1 = std::min(std::max(m0 + 1, 0), src_levels - 1);
+    s.pad0 = s.pad1 = 0.0f;
+    out[n++] = s;
+    total += ndotl;
+  }
+  *total_weight = total;
+  return n;
+}
+
+int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
+  const size_t nv = (size_t)c->n_verts * c->n_instances;
+  const size_t ntri = (size_t)(c->n_indices / 3) * c->n_instances;
+  bool grew = false;
+  if (nv > c->vout_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_vout);
+    HIP_TRY(c, hipMalloc(&c->d_vout, nv * sizeof(VertexOut)));
+    c->vout_cap = nv; grew = true;
+  }
+  const size_t want_setup = ntri + ntri / 4 + 4096;
+  if (want_setup > c->setup_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_setup); free_dev(c->d_bin_list);
+    HIP_TRY(c, hipMalloc(&c->d_setup, want_setup * sizeof(SetupTri)));
+    c->setup_cap = want_setup;
+    c->bin_cap = want_setup * 8 + (1u << 20);
+    HIP_TRY(c, hipMalloc(&c->d_bin_list, c->bin_cap * sizeof(uint32_t)));
+    grew = true;
+  }
+  if ((size_t)n_tiles > c->tile_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_tile_count); free_dev(c->d_tile_offset); free_dev(c->d_tile_cursor);
+    HIP_TRY(c, hipMalloc(&c->d_tile_count, sizeof(uint32_t) * n_tiles));
+    HIP_TRY(c, hipMalloc(&c->d_tile_offset, sizeof(uint32_t) * n_tiles));
+    HIP_TRY(c, hipMalloc(&c->d_tile_cursor, sizeof(uint32_t) * n_tiles));
+    c->tile_cap = n_tiles; grew = true;
+  }
+  const size_t npix = (size_t)W * rows;
+  if (npix > c->pix_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
+    HIP_TRY(c, hipMalloc(&c->d_vis, npix * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_depth, npix * sizeof(float)));
+    HIP_TRY(c, hipMalloc(&c->d_color, npix * 4));
+    c->pix_cap = npix; grew = true;
+  }
+  (void)grew;
+  return PBR_OK;
+}
+
+constexpr int PARAM_SLOTS = 16;
+struct ParamRing {
+  FrameParams* host = nullptr;   // pinned
+  FrameParams* dev = nullptr;
+  hipEvent_t done[PARAM_SLOTS] = {};
+  bool used[PARAM_SLOTS] = {};
+  int next = 0;
+};
+
+}  // namespace
+
+// The ring lives behind the context; keeping it out of the header keeps PbrContext plain.
+struct PbrContextPrivate {
+  ParamRing ring;
+  float* d_srgb_lut = nullptr;
+  int prefilter_tables_for = -1;          // mips the cached sample tables were built for
+  int prefilter_src_levels = -1;
+  int table_count[PBR_MAX_LEVELS] = {};
+  float table_weight[PBR_MAX_LEVELS] = {};
+  uint32_t frames_drawn = 0;
+};
+static PbrContextPrivate* priv_of(PbrContext* c);
+
+namespace {
+struct CtxBox { PbrContext pub; PbrContextPrivate priv; };
+}
+static PbrContextPrivate* priv_of(PbrContext* c) { return &reinterpret_cast<CtxBox*>(c)->priv; }
+
+static int check_sticky(PbrContext* c) {
+  // counters[2] is set by the binning kernels when a capacity was exceeded
+  if (c->h_counters && c->h_counters[2]) {
+    uint32_t code = c->h_counters[2];
+    c->h_counters[2] = 0;
+    return fail(c, PBR_E_STATE, code == 1 ? "triangle setup buffer overflow" : "tile bin list overflow");
+  }
+  return PBR_OK;
+}
+
+static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, int y0, int y1, void* d_rgba8, void* d_vis, PbrFrameStats* stats) {
+  if (!u) return fail(c, PBR_E_ARG, "uniforms pointer is null");
+  if (W <= 0 || H <= 0 || W > 16384 || H > 16384) return fail(c, PBR_E_ARG, "bad target size %dx%d", W, H);
+  if (y0 < 0 || y1 > H || y0 >= y1 || (y0 & 1) || ((y1 & 1) && y1 != H)) return fail(c, PBR_E_ARG, "bad row range [%d,%d) for height %d (rows must start and end on even lines)", y0, y1, H);
+  if (u->sampler_index & ~15u) return fail(c, PBR_E_UNSUPPORTED, "sampler index %u selects the MSAA pipeline, which is not implemented", u->sampler_index);
+  if (!c->d_vsoa) return fail(c, PBR_E_STATE, "no mesh uploaded");
+  for (int i = 0; i < 5; ++i) if (!c->d_tex[i]) return fail(c, PBR_E_STATE, "material texture slot %d not uploaded", i);
+  if (!c->d_irr) return fail(c, PBR_E_STATE, "irradiance map not generated");
+  if (!c->d_pre) return fail(c, PBR_E_STATE, "prefilter map not generated");
+  if (!c->d_lut) return fail(c, PBR_E_STATE, "BRDF LUT not generated");
+  if (!c->d_sky) return fail(c, PBR_E_STATE, "skybox cube not generated");
+  if (c->has_instance_mats == false && c->n_instances != 1) return fail(c, PBR_E_STATE, "instanced mesh without instance matrices");
+  DeviceGuard guard(c->device);
+  PbrContextPrivate* pr = priv_of(c);
+
+  const int rows = y1 - y0;
+  const int tiles_x = (W + PBR_TILE - 1) / PBR_TILE, tiles_y = (rows + PBR_TILE - 1) / PBR_TILE;
+  int rc = ensure_frame_buffers(c, W, rows, tiles_x * tiles_y);
+  if (rc) return rc;
+
+  // stage the per-frame parameters
+  ParamRing& ring = pr->ring;
+  const int slot = ring.next;
+  ring.next = (ring.next + 1) % PARAM_SLOTS;
+  if (ring.used[slot]) HIP_TRY(c, hipEventSynchronize(ring.done[slot]));
+  FrameParams& fp = ring.host[slot];
+  fp.u = *u;
+  mat4_mul_host(u->projection, u->view, fp.pv);
+  fp.W = W; fp.H = H; fp.y0 = y0; fp.y1 = y1; fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
+  fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances;
+  fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
+  FrameParams* dp = ring.dev + slot;
+  hipStream_t s = c->stream;
+  HIP_TRY(c, hipMemcpyAsync(dp, &fp, sizeof(FrameParams), hipMemcpyHostToDevice, s));
+  HIP_TRY(c, hipEventRecord(ring.done[slot], s));
+  ring.used[slot] = true;
+
+  const bool timed = stats != nullptr;
+  const bool prof = c->profiling && c->prof_frames < c->prof_cap;
+  if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], s));
+  if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames], s));
+
+  launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances);
+  if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+  launch_setup_and_bin(s, dp, c->d_vout, c->d_indices, c->d_setup, (uint32_t)c->setup_cap, c->d_tile_count, c->d_tile_offset, c->d_tile_cursor,
+                       c->d_bin_list, (uint32_t)c->bin_cap, c->d_counters, c->n_indices / 3, c->n_instances, tiles_x * tiles_y);
+  if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
+  uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
+  launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_tile_offset, c->d_bin_list, vis, c->d_depth, tiles_x, tiles_y);
+  if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
+  if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames + 1], s));
+
+  ResolveInputs in;
+  in.vout = c->d_vout; in.indices = c->d_indices;
+  for (int i = 0; i < 5; ++i) in.tex[i] = c->tex[i];
+  in.irr = c->irr; in.pre = c->pre; in.sky = c->sky;
+  in.lut = c->d_lut; in.lut_size = c->lut_size;
+  launch_resolve(s, dp, in, pr->d_srgb_lut, vis, static_cast<uint8_t*>(d_rgba8), &c->d_counters[3], W, rows);
+  if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
+  if (prof) { HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames + 2], s)); ++c->prof_frames; }
+  HIP_TRY(c, hipGetLastError());
+  c->last_w = W; c->last_rows = rows;
+  ++pr->frames_drawn;
+
+  if (timed) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    (void)hipEventElapsedTime(&stats->ms_vertex, c->ev[0], c->ev[1]);
+    (void)hipEventElapsedTime(&stats->ms_setup, c->ev[1], c->ev[2]);
+    (void)hipEventElapsedTime(&stats->ms_raster, c->ev[2], c->ev[3]);
+    (void)hipEventElapsedTime(&stats->ms_resolve, c->ev[3], c->ev[4]);
+    (void)hipEventElapsedTime(&stats->ms_total, c->ev[0], c->ev[4]);
+    stats->setup_triangles = c->h_counters[0];
+    stats->binned_refs = c->h_counters[1];
+    stats->covered_pixels = c->h_counters[3];
+    stats->reserved = 0;
+    return check_sticky(c);
+  }
+  return PBR_OK;
+}
+
+extern "C" {
+
+int pbr_create(int device_ordinal, PbrContext** ctx_out) {
+  if (!ctx_out) return fail(nullptr, PBR_E_ARG, "ctx_out is null");
+  *ctx_out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return fail(nullptr, PBR_E_DEVICE, "no HIP device available (%s)", e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+  if (device_ordinal < 0 || device_ordinal >= count) return fail(nullptr, PBR_E_ARG, "device ordinal %d out of range (0..%d)", device_ordinal, count - 1);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return fail(nullptr, PBR_E_DEVICE, "cannot query device %d", device_ordinal);
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, PBR_E_DEVICE, "device %d is %s; this library carries gfx950 code only", device_ordinal, prop.gcnArchName);
+  CtxBox* box = new CtxBox();
+  PbrContext* c = &box->pub;
+  c->device = device_ordinal;
+  DeviceGuard guard(device_ordinal);
+  auto bail = [&](const char* what, hipError_t err) {
+    int rc = fail(nullptr, PBR_E_DEVICE, "%s failed: %s", what, hipGetErrorString(err));
+    pbr_destroy(c);
+    return rc;
+  };
+  if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
+  c->stream = c->own_stream;
+  for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipMalloc(&c->d_counters, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(c->d_counters, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
+  if ((e = hipHostMalloc(&c->h_counters, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
+  std::memset(c->h_counters, 0, 4 * sizeof(uint32_t));
+  ParamRing& ring = box->priv.ring;
+  if ((e = hipHostMalloc(&ring.host, PARAM_SLOTS * sizeof(FrameParams))) != hipSuccess) return bail("hipHostMalloc", e);
+  if ((e = hipMalloc(&ring.dev, PARAM_SLOTS * sizeof(FrameParams))) != hipSuccess) return bail("hipMalloc", e);
+  for (auto& ev : ring.done) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
+  if ((e = hipMalloc(&c->d_samples, sizeof(PrefilterSample) * PBR_PREFILTER_SAMPLES * PBR_MAX_LEVELS)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMalloc(&c->d_irr_tables, sizeof(float) * 2 * (512 + 128))) != hipSuccess) return bail("hipMalloc", e);
+  {
+    float lut[256];   // sRGB transfer function of the rgba8unorm-srgb formats (renderer.ts:647, :697)
+    for (int i = 0; i < 256; ++i) { float v = (float)i / 255.0f; lut[i] = v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f); }
+    if ((e = hipMalloc(&box->priv.d_srgb_lut, sizeof lut)) != hipSuccess) return bail("hipMalloc", e);
+    if ((e = hipMemcpy(box->priv.d_srgb_lut, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
+  }
+  *ctx_out = c;
+  return PBR_OK;
+}
+
+int pbr_destroy(PbrContext* c) {
+  if (!c) return PBR_OK;
+  DeviceGuard guard(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  PbrContextPrivate* pr = priv_of(c);
+  free_dev(c->d_vsoa); free_dev(c->d_indices); free_dev(c->d_inst_model); free_dev(c->d_inst_normal);
+  for (auto& t : c->d_tex) free_dev(t);
+  free_dev(c->d_hdr); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
+  free_dev(c->d_samples); free_dev(c->d_irr_tables);
+  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_tile_count); free_dev(c->d_tile_offset); free_dev(c->d_tile_cursor);
+  free_dev(c->d_bin_list); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
+  free_dev(pr->ring.dev); free_dev(pr->d_srgb_lut);
+  if (pr->ring.host) (void)hipHostFree(pr->ring.host);
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
+  for (auto& ev : pr->ring.done) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->prof_events) if (ev) (void)hipEventDestroy(ev);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete reinterpret_cast<CtxBox*>(c);
+  return PBR_OK;
+}
+
+const char* pbr_last_error(const PbrContext* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+
+int pbr_set_stream(PbrContext* c, void* hip_stream) {
+  if (!c) return PBR_E_ARG;
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return PBR_OK;
+}
+
+int pbr_synchronize(PbrContext* c) {
+  if (!c) return PBR_E_ARG;
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return check_sticky(c);
+}
+
+int pbr_upload_mesh(PbrContext* c, const float* verts, int32_t n_verts, const uint16_t* indices, int32_t n_indices,
+                    int32_t instance_count, const float* instance_model, const float* instance_normal) {
+  if (!c) return PBR_E_ARG;
+  if (!verts || !indices || n_verts <= 0 || n_indices <= 0) return fail(c, PBR_E_ARG, "empty mesh");
+  if (n_indices % 3) return fail(c, PBR_E_ARG, "index count %d is not a multiple of 3 (triangle-list)", n_indices);
+  if (instance_count < 1) return fail(c, PBR_E_ARG, "instance count must be at least 1");
+  if (instance_count > 1 && (!instance_model || !instance_normal)) return fail(c, PBR_E_ARG, "instanced upload needs model and normal matrices");
+  if ((uint64_t)instance_count * (uint64_t)(n_indices / 3) >= 0xffffffffull) return fail(c, PBR_E_ARG, "too many triangles for 32-bit visibility ids");
+  for (int32_t i = 0; i < n_indices; ++i) if (indices[i] >= n_verts) return fail(c, PBR_E_ARG, "index %d refers to vertex %u of %d", i, indices[i], n_verts);
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  free_dev(c->d_vsoa); free_dev(c->d_indices); free_dev(c->d_inst_model); free_dev(c->d_inst_normal);
+  std::vector<float> soa((size_t)n_verts * 8);
+  for (int32_t i = 0; i < n_verts; ++i) {
+    const float* v = verts + 8 * (size_t)i;   // pos3, uv2, normal3 (glTF.ts:193-213)
+    soa[i] = v[0]; soa[(size_t)n_verts + i] = v[1]; soa[2 * (size_t)n_verts + i] = v[2];
+    soa[3 * (size_t)n_verts + i] = v[3]; soa[4 * (size_t)n_verts + i] = v[4];
+    soa[5 * (size_t)n_verts + i] = v[5]; soa[6 * (size_t)n_verts + i] = v[6]; soa[7 * (size_t)n_verts + i] = v[7];
+  }
+  HIP_TRY(c, hipMalloc(&c->d_vsoa, soa.size() * sizeof(float)));
+  HIP_TRY(c, hipMemcpy(c->d_vsoa, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMalloc(&c->d_indices, (size_t)n_indices * sizeof(uint16_t)));
+  HIP_TRY(c, hipMemcpy(c->d_indices, indices, (size_t)n_indices * sizeof(uint16_t), hipMemcpyHostToDevice));
+  c->has_instance_mats = instance_model && instance_normal;
+  if (c->has_instance_mats) {
+    const size_t bytes = (size_t)instance_count * 16 * sizeof(float);
+    HIP_TRY(c, hipMalloc(&c->d_inst_model, bytes));
+    HIP_TRY(c, hipMalloc(&c->d_inst_normal, bytes));
+    HIP_TRY(c, hipMemcpy(c->d_inst_model, instance_model, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->d_inst_normal, instance_normal, bytes, hipMemcpyHostToDevice));
+  }
+  c->n_verts = n_verts; c->n_indices = n_indices; c->n_instances = instance_count;
+  return PBR_OK;
+}
+
+int pbr_upload_texture(PbrContext* c, int slot, const uint8_t* rgba8, int32_t w, int32_t h, int32_t is_srgb, int32_t gen_mips) {
+  if (!c) return PBR_E_ARG;
+  if (slot < 0 || slot > 4) return fail(c, PBR_E_ARG, "texture slot %d out of range", slot);
+  if (!rgba8 || w <= 0 || h <= 0 || w > 16384 || h > 16384) return fail(c, PBR_E_ARG, "bad texture %dx%d", w, h);
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  free_dev(c->d_tex[slot]);
+  DevTex8& t = c->tex[slot];
+  t.w = w; t.h = h; t.srgb = is_srgb ? 1 : 0;
+  t.levels = gen_mips ? level_count(w, h) : 1;
+  if (t.levels > PBR_MAX_LEVELS) return fail(c, PBR_E_ARG, "too many mip levels");
+  size_t total;
+  chain_offsets(w, h, t.levels, t.off, &total);
+  HIP_TRY(c, hipMalloc(&c->d_tex[slot], total * sizeof(uint32_t)));
+  t.base = c->d_tex[slot];
+  HIP_TRY(c, hipMemcpyAsync(c->d_tex[slot], rgba8, (size_t)w * h * 4, hipMemcpyHostToDevice, c->stream));
+  if (t.levels > 1) launch_build_mips_rgba8(c->stream, c->d_tex[slot], t.off, w, h, t.levels, t.srgb);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  c->tex_has_mips[slot] = t.levels > 1;
+  return PBR_OK;
+}
+
+int pbr_upload_hdr(PbrContext* c, const float* rgba32f, int32_t w, int32_t h) {
+  if (!c) return PBR_E_ARG;
+  if (!rgba32f || w <= 0 || h <= 0 || w > 32768 || h > 32768) return fail(c, PBR_E_ARG, "bad HDR %dx%d", w, h);
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  free_dev(c->d_hdr);
+  DevEquirect& e = c->hdr;
+  e.w = w; e.h = h; e.levels = level_count(w, h);   // renderer.ts:1513
+  if (e.levels > PBR_MAX_LEVELS) return fail(c, PBR_E_ARG, "too many mip levels");
+  size_t total;
+  chain_offsets(w, h, e.levels, e.off, &total);
+  HIP_TRY(c, hipMalloc(&c->d_hdr, total * sizeof(float4)));
+  e.base = c->d_hdr;
+  HIP_TRY(c, hipMemcpyAsync(c->d_hdr, rgba32f, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  launch_build_mips_rgba32f(c->stream, c->d_hdr, e.off, w, h, e.levels);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  priv_of(c)->prefilter_tables_for = -1;
+  return PBR_OK;
+}
+
+int pbr_ibl_equirect_to_cube(PbrContext* c, int32_t size) {
+  if (!c) return PBR_E_ARG;
+  if (size <= 0 || size > 8192) return fail(c, PBR_E_ARG, "bad cube size %d", size);
+  if (!c->d_hdr) return fail(c, PBR_E_STATE, "no HDR uploaded");
+  DeviceGuard guard(c->device);
+  if (c->sky.size != size || !c->d_sky) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_sky);
+    size_t total;
+    cube_offsets(size, 1, c->sky.off, &total);
+    HIP_TRY(c, hipMalloc(&c->d_sky, total * sizeof(float4)));
+    c->sky.base = c->d_sky; c->sky.size = size; c->sky.levels = 1;
+  }
+  launch_equirect_to_cube(c->stream, c->hdr, c->d_sky, size);
+  HIP_TRY(c, hipGetLastError());
+  return PBR_OK;
+}
+
+int pbr_ibl_irradiance(PbrContext* c, int32_t size) {
+  if (!c) return PBR_E_ARG;
+  if (size <= 0 || size > 2048) return fail(c, PBR_E_ARG, "bad cube size %d", size);
+  if (!c->d_hdr) return fail(c, PBR_E_STATE, "no HDR uploaded");
+  DeviceGuard guard(c->device);
+  if (c->irr.size != size || !c->d_irr) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_irr);
+    size_t total;
+    cube_offsets(size, 1, c->irr.off, &total);
+    HIP_TRY(c, hipMalloc(&c->d_irr, total * sizeof(float4)));
+    c->irr.base = c->d_irr; c->irr.size = size; c->irr.levels = 1;
+  }
+  // The angles the reference's f32 loop counters take (irradiancemap.wgsl:73-76): 252 x 63 steps.
+  const float PI = 3.14159265359f, delta = 0.025f;
+  std::vector<float> cp, sp, st, ct;
+  for (float phi = 0.0f; phi < 2.0f * PI; phi += delta) { cp.push_back(std::cos(phi)); sp.push_back(std::sin(phi)); }
+  for (float th = 0.0f; th < 0.5f * PI; th += delta) { st.push_back(std::sin(th)); ct.push_back(std::cos(th)); }
+  const int n_phi = (int)cp.size(), n_theta = (int)st.size();
+  if (n_phi > 512 || n_theta > 128) return fail(c, PBR_E_STATE, "irradiance tables too large");
+  std::vector<float> tables;
+  tables.insert(tables.end(), cp.begin(), cp.end()); tables.insert(tables.end(), sp.begin(), sp.end());
+  tables.insert(tables.end(), st.begin(), st.end()); tables.insert(tables.end(), ct.begin(), ct.end());
+  HIP_TRY(c, hipMemcpy(c->d_irr_tables, tables.data(), tables.size() * sizeof(float), hipMemcpyHostToDevice));
+  launch_irradiance(c->stream, c->hdr, c->d_irr_tables, n_phi, n_theta, c->d_irr, size);
+  HIP_TRY(c, hipGetLastError());
+  return PBR_OK;
+}
+
+static void prefilter_total(const PbrContext* c, size_t* texels) { *texels = c->pre_total_texels; }
+
+int pbr_ibl_prefilter_shard_range(PbrContext* c, int32_t shard_index, int32_t shard_count, size_t* begin, size_t* end) {
+  if (!c || !begin || !end) return PBR_E_ARG;
+  if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail(c, PBR_E_ARG, "bad shard %d of %d", shard_index, shard_count);
+  if (!c->d_pre) return fail(c, PBR_E_STATE, "prefilter map not allocated; call pbr_ibl_prefilter first");
+  size_t total;
+  prefilter_total(c, &total);
+  *begin = total * (size_t)shard_index / (size_t)shard_count * sizeof(float4);
+  *end = total * (size_t)(shard_index + 1) / (size_t)shard_count * sizeof(float4);
+  return PBR_OK;
+}
+
+int pbr_ibl_prefilter(PbrContext* c, int32_t size, int32_t mips, int32_t samples, int32_t shard_index, int32_t shard_count) {
+  if (!c) return PBR_E_ARG;
+  if (size <= 0 || size > 8192) return fail(c, PBR_E_ARG, "bad cube size %d", size);
+  if (mips < 1 || mips > PBR_MAX_LEVELS || (size >> (mips - 1)) < 1) return fail(c, PBR_E_ARG, "bad mip count %d for size %d", mips, size);
+  if (samples != PBR_PREFILTER_SAMPLES) return fail(c, PBR_E_UNSUPPORTED, "sample count %d: the reference fixes SAMPLE_COUNT at 1024", samples);
+  if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail(c, PBR_E_ARG, "bad shard %d of %d", shard_index, shard_count);
+  if (!c->d_hdr) return fail(c, PBR_E_STATE, "no HDR uploaded");
+  DeviceGuard guard(c->device);
+  PbrContextPrivate* pr = priv_of(c);
+  if (c->pre.size != size || c->pre.levels != mips || !c->d_pre) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_pre);
+    size_t total;
+    cube_offsets(size, mips, c->pre.off, &total);
+    HIP_TRY(c, hipMalloc(&c->d_pre, total * sizeof(float4)));
+    HIP_TRY(c, hipMemset(c->d_pre, 0, total * sizeof(float4)));
+    c->pre.base = c->d_pre; c->pre.size = size; c->pre.levels = mips;
+    c->pre_total_texels = total;
+    pr->prefilter_tables_for = -1;
+  }
+  if (pr->prefilter_tables_for != mips || pr->prefilter_src_levels != c->hdr.levels) {
+    std::vector<PrefilterSample> host((size_t)PBR_PREFILTER_SAMPLES * mips);
+    for (int m = 0; m < mips; ++m) {
+      // renderer.ts:1559: roughness = mip / (maxMipLevels - 1) stored as f32; a single level gets 0
+      const float roughness = mips > 1 ? (float)((double)m / (double)(mips - 1)) : 0.0f;
+      pr->table_count[m] = build_prefilter_table(roughness, c->hdr.levels, host.data() + (size_t)m * PBR_PREFILTER_SAMPLES, &pr->table_weight[m]);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(c->d_samples, host.data(), host.size() * sizeof(PrefilterSample), hipMemcpyHostToDevice));
+    pr->prefilter_tables_for = mips; pr->prefilter_src_levels = c->hdr.levels;
+  }
+  const size_t total = c->pre_total_texels;
+  const size_t begin = total * (size_t)shard_index / (size_t)shard_count, end = total * (size_t)(shard_index + 1) / (size_t)shard_count;
+  for (int m = 0; m < mips; ++m) {
+    const size_t s = (size_t)std::max(1, size >> m);
+    const size_t lo = c->pre.off[m], hi = lo + 6 * s * s;
+    const size_t a = std::max(lo, begin), b = std::min(hi, end);
+    if (a >= b) continue;
+    launch_prefilter(c->stream, c->hdr, c->d_samples + (size_t)m * PBR_PREFILTER_SAMPLES, pr->table_count[m], pr->table_weight[m],
+                     c->d_pre + lo, (int)s, (int64_t)(a - lo), (int64_t)(b - a));
+  }
+  HIP_TRY(c, hipGetLastError());
+  return PBR_OK;
+}
+
+int pbr_ibl_brdf_lut(PbrContext* c, int32_t size) {
+  if (!c) return PBR_E_ARG;
+  if (size < 2 || size > 8192) return fail(c, PBR_E_ARG, "bad LUT size %d", size);
+  DeviceGuard guard(c->device);
+  if (c->lut_size != size || !c->d_lut) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_lut);
+    HIP_TRY(c, hipMalloc(&c->d_lut, (size_t)size * size * 4 * sizeof(uint16_t)));
+    c->lut_size = size;
+  }
+  launch_brdf_lut(c->stream, c->d_lut, size);
+  HIP_TRY(c, hipGetLastError());
+  return PBR_OK;
+}
+
+static int map_level(PbrContext* c, int which, int level, const void** ptr, int* w, int* h, int* layers, size_t* bytes) {
+  switch (which) {
+    case PBR_MAP_SKYBOX:
+    case PBR_MAP_IRRADIANCE:
+    case PBR_MAP_PREFILTER: {
+      const DevCube& m = which == PBR_MAP_SKYBOX ? c->sky : which == PBR_MAP_IRRADIANCE ? c->irr : c->pre;
+      if (!m.base) return fail(c, PBR_E_STATE, "map %d not generated", which);
+      if (level < 0 || level >= m.levels) return fail(c, PBR_E_ARG, "level %d out of range", level);
+      const int s = std::max(1, m.size >> level);
+      *ptr = m.base + m.off[level]; *w = s; *h = s; *layers = 6; *bytes = (size_t)6 * s * s * sizeof(float4);
+      return PBR_OK;
+    }
+    case PBR_MAP_BRDF_LUT:
+      if (!c->d_lut) return fail(c, PBR_E_STATE, "BRDF LUT not generated");
+      if (level != 0) return fail(c, PBR_E_ARG, "level %d out of range", level);
+      *ptr = c->d_lut; *w = c->lut_size; *h = c->lut_size; *layers = 1; *bytes = (size_t)c->lut_size * c->lut_size * 4 * sizeof(uint16_t);
+      return PBR_OK;
+    case PBR_MAP_HDR:
+      if (!c->d_hdr) return fail(c, PBR_E_STATE, "no HDR uploaded");
+      if (level < 0 || level >= c->hdr.levels) return fail(c, PBR_E_ARG, "level %d out of range", level);
+      *w = std::max(1, c->hdr.w >> level); *h = std::max(1, c->hdr.h >> level); *layers = 1;
+      *ptr = c->hdr.base + c->hdr.off[level]; *bytes = (size_t)*w * *h * sizeof(float4);
+      return PBR_OK;
+    default:
+      return fail(c, PBR_E_ARG, "unknown map %d", which);
+  }
+}
+
+int pbr_ibl_level_info(PbrContext* c, int which, int32_t level, int32_t* w, int32_t* h, int32_t* layers, size_t* bytes) {
+  if (!c) return PBR_E_ARG;
+  const void* p; int ww, hh, ll; size_t bb;
+  int rc = map_level(c, which, level, &p, &ww, &hh, &ll, &bb);
+  if (rc) return rc;
+  if (w) *w = ww;
+  if (h) *h = hh;
+  if (layers) *layers = ll;
+  if (bytes) *bytes = bb;
+  return PBR_OK;
+}
+
+int pbr_ibl_download(PbrContext* c, int which, int32_t level, void* out, size_t out_bytes) {
+  if (!c || !out) return PBR_E_ARG;
+  const void* p; int w, h, l; size_t bytes;
+  int rc = map_level(c, which, level, &p, &w, &h, &l, &bytes);
+  if (rc) return rc;
+  if (out_bytes < bytes) return fail(c, PBR_E_ARG, "output buffer holds %zu bytes, level needs %zu", out_bytes, bytes);
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(out, p, bytes, hipMemcpyDeviceToHost));
+  return PBR_OK;
+}
+
+int pbr_ibl_device_ptr(PbrContext* c, int which, void** dev_ptr, size_t* total_bytes) {
+  if (!c || !dev_ptr) return PBR_E_ARG;
+  size_t bytes = 0;
+  void* p = nullptr;
+  switch (which) {
+    case PBR_MAP_SKYBOX: p = c->d_sky; bytes = (size_t)6 * c->sky.size * c->sky.size * sizeof(float4); break;
+    case PBR_MAP_IRRADIANCE: p = c->d_irr; bytes = (size_t)6 * c->irr.size * c->irr.size * sizeof(float4); break;
+    case PBR_MAP_PREFILTER: p = c->d_pre; bytes = c->pre_total_texels * sizeof(float4); break;
+    case PBR_MAP_BRDF_LUT: p = c->d_lut; bytes = (size_t)c->lut_size * c->lut_size * 4 * sizeof(uint16_t); break;
+    case PBR_MAP_HDR: { p = c->d_hdr; size_t t; uint32_t off[PBR_MAX_LEVELS]; chain_offsets(c->hdr.w, c->hdr.h, c->hdr.levels, off, &t); bytes = t * sizeof(float4); break; }
+    default: return fail(c, PBR_E_ARG, "unknown map %d", which);
+  }
+  if (!p) return fail(c, PBR_E_STATE, "map %d not generated", which);
+  *dev_ptr = p;
+  if (total_bytes) *total_bytes = bytes;
+  return PBR_OK;
+}
+
+int pbr_draw_frame_device(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1, void* d_rgba8, void* d_vis,
+                          PbrFrameStats* stats) {
+  if (!c) return PBR_E_ARG;
+  if (!d_rgba8) return fail(c, PBR_E_ARG, "colour output pointer is null");
+  return draw_common(c, u, w, h, y0, y1, d_rgba8, d_vis, stats);
+}
+
+int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1, uint8_t* rgba8_out, uint32_t* vis_out,
+                   PbrFrameStats* stats) {
+  if (!c) return PBR_E_ARG;
+  if (!rgba8_out) return fail(c, PBR_E_ARG, "colour output pointer is null");
+  if (w <= 0 || h <= 0 || y0 < 0 || y1 > h || y0 >= y1) return fail(c, PBR_E_ARG, "bad target %dx%d rows [%d,%d)", w, h, y0, y1);
+  DeviceGuard guard(c->device);
+  // make sure the internal colour / visibility buffers exist at this size before drawing into them
+  const int rows = y1 - y0;
+  int rc = ensure_frame_buffers(c, w, rows, ((w + PBR_TILE - 1) / PBR_TILE) * ((rows + PBR_TILE - 1) / PBR_TILE));
+  if (rc) return rc;
+  rc = draw_common(c, u, w, h, y0, y1, c->d_color, nullptr, stats);
+  if (rc) return rc;
+  const size_t npix = (size_t)w * rows;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(rgba8_out, c->d_color, npix * 4, hipMemcpyDeviceToHost));
+  if (vis_out) HIP_TRY(c, hipMemcpy(vis_out, c->d_vis, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return check_sticky(c);
+}
+
+int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip, float* world, float* normal) {
+  if (!c || !u) return PBR_E_ARG;
+  if (!c->d_vsoa) return fail(c, PBR_E_STATE, "no mesh uploaded");
+  DeviceGuard guard(c->device);
+  int rc = ensure_frame_buffers(c, 32, 32, 1);
+  if (rc) return rc;
+  PbrContextPrivate* pr = priv_of(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  FrameParams& fp = pr->ring.host[0];
+  fp.u = *u;
+  mat4_mul_host(u->projection, u->view, fp.pv);
+  fp.W = 32; fp.H = 32; fp.y0 = 0; fp.y1 = 32; fp.tiles_x = 1; fp.tiles_y = 1;
+  fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances; fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
+  HIP_TRY(c, hipMemcpy(pr->ring.dev, &fp, sizeof fp, hipMemcpyHostToDevice));
+  launch_vertex_stage(c->stream, pr->ring.dev, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const size_t nv = (size_t)c->n_verts * c->n_instances;
+  std::vector<VertexOut> host(nv);
+  HIP_TRY(c, hipMemcpy(host.data(), c->d_vout, nv * sizeof(VertexOut), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < nv; ++i) {
+    if (clip) { clip[4 * i] = host[i].clip.x; clip[4 * i + 1] = host[i].clip.y; clip[4 * i + 2] = host[i].clip.z; clip[4 * i + 3] = host[i].clip.w; }
+    if (world) { world[3 * i] = host[i].world_u.x; world[3 * i + 1] = host[i].world_u.y; world[3 * i + 2] = host[i].world_u.z; }
+    if (normal) { normal[3 * i] = host[i].nrm_v.x; normal[3 * i + 1] = host[i].nrm_v.y; normal[3 * i + 2] = host[i].nrm_v.z; }
+  }
+  return PBR_OK;
+}
+
+int pbr_debug_depth(PbrContext* c, float* depth_out, size_t n_floats) {
+  if (!c || !depth_out) return PBR_E_ARG;
+  const size_t n = (size_t)c->last_w * c->last_rows;
+  if (!c->d_depth || n == 0) return fail(c, PBR_E_STATE, "no frame drawn yet");
+  if (n_floats < n) return fail(c, PBR_E_ARG, "depth buffer needs %zu floats", n);
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpy(depth_out, c->d_depth, n * sizeof(float), hipMemcpyDeviceToHost));
+  return PBR_OK;
+}
+
+int pbr_profile_begin(PbrContext* c, int32_t max_frames) {
+  if (!c || max_frames <= 0 || max_frames > (1 << 20)) return c ? fail(c, PBR_E_ARG, "bad frame count") : PBR_E_ARG;
+  DeviceGuard guard(c->device);
+  while ((int)c->prof_events.size() < 3 * max_frames) {
+    hipEvent_t ev;
+    HIP_TRY(c, hipEventCreate(&ev));
+    c->prof_events.push_back(ev);
+  }
+  c->prof_cap = max_frames; c->prof_frames = 0; c->profiling = true;
+  return PBR_OK;
+}
+
+int pbr_profile_end(PbrContext* c, int32_t* frames, float* resolve_ms_total, float* raster_ms_total, float* frame_ms_total) {
+  if (!c) return PBR_E_ARG;
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  float resolve = 0, geom = 0, total = 0;
+  for (int i = 0; i < c->prof_frames; ++i) {
+    float a = 0, b = 0;
+    HIP_TRY(c, hipEventElapsedTime(&a, c->prof_events[3 * i], c->prof_events[3 * i + 1]));
+    HIP_TRY(c, hipEventElapsedTime(&b, c->prof_events[3 * i + 1], c->prof_events[3 * i + 2]));
+    geom += a; resolve += b; total += a + b;
+  }
+  if (frames) *frames = c->prof_frames;
+  if (resolve_ms_total) *resolve_ms_total = resolve;
+  if (raster_ms_total) *raster_ms_total = geom;
+  if (frame_ms_total) *frame_ms_total = total;
+  c->profiling = false;
+  return PBR_OK;
+}
+
+}  // extern "C"

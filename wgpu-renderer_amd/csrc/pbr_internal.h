@@ -1,0 +1,143 @@
+// Internal declarations shared by the translation units of libpbr355.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/pbr355.h"
+
+#define PBR_MAX_LEVELS 16
+#define PBR_TILE 32               // raster tile edge in pixels (one 256-thread workgroup, 2x2 pixels per thread)
+#define PBR_SUBPIXEL_BITS 8
+#define PBR_GUARD 8.0f            // guard band in units of w
+#define PBR_PREFILTER_SAMPLES 1024
+
+// An rgba8 texture with its mip chain in one allocation.
+struct DevTex8 {
+  const uint32_t* base;           // packed r | g<<8 | b<<16 | a<<24
+  uint32_t off[PBR_MAX_LEVELS];   // texel offset of each level
+  int32_t w, h, levels, srgb;
+};
+
+// A cube map (or its mip chain) of rgba32f texels: level l is [6][size>>l][size>>l].
+struct DevCube {
+  const float4* base;
+  uint32_t off[PBR_MAX_LEVELS];
+  int32_t size, levels;
+};
+
+// An equirectangular rgba32f image with its mip chain.
+struct DevEquirect {
+  const float4* base;
+  uint32_t off[PBR_MAX_LEVELS];
+  int32_t w, h, levels;
+};
+
+// One importance sample of the GGX prefilter, in the tangent frame of the output texel.
+struct PrefilterSample {
+  float lx, ly, lz;   // light direction; lz is also N.L, the weight
+  float mix;          // blend between source levels l0 and l0+1
+  int32_t l0, l1;
+  float pad0, pad1;
+};
+
+// Snapped, front-facing triangle as the rasteriser consumes it (48 bytes).
+struct SetupTri {
+  int32_t X[3], Y[3];   // vertices in 1/256 pixel, ordered so edge functions are positive inside
+  float z0, dz1, dz2;   // depth at vertex 0 and its differences to vertices 1 and 2
+  float inv_area;       // 1 / (twice the signed area), f32
+  uint32_t id;          // global triangle id
+  uint32_t pad;
+};
+
+// Per-vertex outputs of the vertex stage, laid out for the resolve's gathers.
+struct VertexOut {
+  float4 clip;      // projection * view * model * position
+  float4 world_u;   // world position xyz, texcoord u
+  float4 nrm_v;     // normal-matrix * normal xyz, texcoord v
+};
+
+struct FrameParams {
+  PbrFrameUniforms u;
+  float pv[16];             // projection * view
+  int32_t W, H, y0, y1;
+  int32_t tiles_x, tiles_y; // tiles covering rows [y0,y1)
+  int32_t n_verts, n_tris, n_instances;
+  int32_t has_instance_mats;
+};
+
+struct PbrContext {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string error;
+
+  // mesh (SoA vertex streams)
+  float* d_vsoa = nullptr;          // 8 streams of n_verts floats: px py pz u v nx ny nz
+  uint16_t* d_indices = nullptr;
+  float* d_inst_model = nullptr;    // [n_instances][16]
+  float* d_inst_normal = nullptr;
+  int32_t n_verts = 0, n_indices = 0, n_instances = 0;
+  bool has_instance_mats = false;
+
+  // material textures
+  uint32_t* d_tex[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  DevTex8 tex[5] = {};
+  bool tex_has_mips[5] = {false, false, false, false, false};
+
+  // HDR + IBL
+  float4* d_hdr = nullptr;
+  DevEquirect hdr = {};
+  float4* d_sky = nullptr;   DevCube sky = {};
+  float4* d_irr = nullptr;   DevCube irr = {};
+  float4* d_pre = nullptr;   DevCube pre = {};
+  size_t pre_total_texels = 0;
+  uint16_t* d_lut = nullptr; int32_t lut_size = 0;
+  PrefilterSample* d_samples = nullptr;   // PBR_MAX_LEVELS tables of 1024
+  float* d_irr_tables = nullptr;
+
+  // frame working set (grown on demand)
+  VertexOut* d_vout = nullptr;    size_t vout_cap = 0;
+  SetupTri* d_setup = nullptr;    size_t setup_cap = 0;
+  uint32_t* d_tile_count = nullptr; uint32_t* d_tile_offset = nullptr; uint32_t* d_tile_cursor = nullptr; size_t tile_cap = 0;
+  uint32_t* d_bin_list = nullptr; size_t bin_cap = 0;
+  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels
+  uint32_t* h_counters = nullptr; // pinned mirror
+  uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0;
+  int32_t last_w = 0, last_rows = 0;
+  FrameParams* d_params = nullptr;
+  FrameParams* h_params = nullptr;   // pinned staging
+
+  // timing
+  hipEvent_t ev[6] = {};
+  bool profiling = false;
+  std::vector<hipEvent_t> prof_events;   // 4 per frame: frame start, raster start, resolve start, end
+  int32_t prof_frames = 0, prof_cap = 0;
+};
+
+// ---- kernel launchers (defined in the .hip files) ----
+void launch_build_mips_rgba32f(hipStream_t s, float4* chain, const uint32_t* off, int w, int h, int levels);
+void launch_build_mips_rgba8(hipStream_t s, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb);
+void launch_equirect_to_cube(hipStream_t s, DevEquirect hdr, float4* out, int size);
+void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int n_phi, int n_theta, float4* out, int size);
+void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, float inv_weight,
+                      float4* out_level, int level_size, int64_t first, int64_t count);
+void launch_brdf_lut(hipStream_t s, uint16_t* out, int size);
+
+void launch_vertex_stage(hipStream_t s, const FrameParams* p, const float* vsoa, const float* inst_model, const float* inst_normal,
+                         VertexOut* out, int n_verts, int n_instances);
+void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
+                          uint32_t setup_cap, uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* bin_list,
+                          uint32_t bin_cap, uint32_t* counters, int n_tris, int n_instances, int n_tiles);
+void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, const uint32_t* tile_count, const uint32_t* tile_offset,
+                   const uint32_t* bin_list, uint32_t* vis, float* depth, int tiles_x, int tiles_y);
+struct ResolveInputs {
+  const VertexOut* vout;
+  const uint16_t* indices;
+  DevTex8 tex[5];
+  DevCube irr, pre, sky;
+  const uint16_t* lut;
+  int32_t lut_size;
+};
+void launch_resolve(hipStream_t s, const FrameParams* p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
+                    uint32_t* covered, int W, int rows);
