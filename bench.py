@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""Benchmark of the PBR frame path on MI355X.
+
+A step is one 3840x2160 DamagedHelmet PBR+IBL frame (vertex transform, binning, tile raster,
+deferred resolve) rendered into device memory with every input already resident in HBM.  With
+--gpus N > 1 the frames of a camera orbit (one `updateCameraRotation(-10, 0)` step per frame) are
+dealt round-robin to the ranks, one process per GPU, no data-path collective: weak scaling.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the resolve kernel, timed with HIP events on the
+stream the kernels run on; `cpu_baseline` is the CPU oracle (a restatement of the reference WGSL,
+not Dawn/SwiftShader) rendering the same frame on the host cores.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--skybox-size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefilter", action="store_true", help="skip the IBL prefilter timing (2048^2, 10 mips)")
+    ap.add_argument("--prefilter-size", type=int, default=2048)
+    ap.add_argument("--prefilter-mips", type=int, default=10)
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, renderer, uniforms, W, H):
+    """Times the oracle on the same 4K frame (raster + shade) on this host's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    import parity_utils as pu
+    lib = pkg._lib
+    g = renderer.geometries[0]
+    t = g.textures
+    images = [pkg.load_image_bitmap(t[k]) for k in ("baseColorURI", "metallicRoughnessURI", "normalURI", "emissiveURI", "occlusionURI")]
+    osc = pu.OracleScene(g, images, renderer.hdrs[0], renderer.skybox_size, renderer.irradiance_size, renderer.prefilter_size,
+                         renderer.prefilter_mips, renderer.lut_size)
+    # The IBL maps are inputs of the frame path; take the ones already computed instead of spending
+    # minutes of CPU time on the precompute, which this baseline does not measure.
+    osc._maps = {
+        "sky": renderer.download_map(lib.MAP_SKYBOX), "irr": renderer.download_map(lib.MAP_IRRADIANCE),
+        "pre": [renderer.download_map(lib.MAP_PREFILTER, m) for m in range(renderer.prefilter_mips)],
+        "lut": renderer.download_map(lib.MAP_BRDF_LUT),
+    }
+    threads = ob.load().orc_num_threads()
+    t0 = time.perf_counter()
+    osc.draw(uniforms, W, H)
+    dt = time.perf_counter() - t0
+    return {"value": W * H / 1e6 / dt, "unit": "Mpix/s", "cores": threads, "kind": "port",
+            "sample": f"one full {W}x{H} frame (raster + shade) by the CPU oracle, {dt:.2f} s, OpenMP {threads} threads"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    W, H = args.width, args.height
+    r = pkg.Renderer(width=W, height=H, device=local_rank, skybox_size=args.skybox_size)
+    r.init()
+    stream = torch.cuda.Stream(dev)           # a real (non-null) stream, so torch events and syncs see the kernels
+    torch.cuda.set_stream(stream)
+    r.set_stream(stream.cuda_stream)
+
+    color = torch.empty((H, W, 4), dtype=torch.uint8, device=dev)
+    # orbit: global frame f is rendered by rank f mod world; one -10 px tumble (1 degree) per frame
+    for _ in range(rank):
+        r.camera.update_camera_rotation(-10.0, 0.0)
+
+    def step():
+        r.draw_frame_device(color.data_ptr())
+        for _ in range(world):
+            r.camera.update_camera_rotation(-10.0, 0.0)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    lib = r._lib
+    pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, args.steps))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    frames, res_ms, geo_ms, tot_ms = C.c_int32(), C.c_float(), C.c_float(), C.c_float()
+    pkg._lib.check(r._ctx, lib.pbr_profile_end(r._ctx, C.byref(frames), C.byref(res_ms), C.byref(geo_ms), C.byref(tot_ms)))
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # coverage of the last frame for the bandwidth model
+    stats = pkg._lib.FrameStats()
+    u_last = r.frame_uniforms()
+    r.draw_frame_device(color.data_ptr(), uniforms=u_last, stats=stats)
+    c = stats.covered_pixels / float(W * H)
+
+    result = None
+    if rank == 0:
+        npix = W * H
+        resolve_ms = res_ms.value / max(frames.value, 1)
+        # algorithmic bytes of one resolve launch: visibility read + colour write per pixel, one
+        # unique rgba8 texel per material texture per covered pixel, one rgba32f skybox texel per
+        # background pixel
+        resolve_bytes = npix * 8 + c * npix * 20 + (1.0 - c) * npix * 16
+        achieved = resolve_bytes / (resolve_ms * 1e-3) / 1e9
+        result = {
+            "metric": "shaded Mpix/s (DamagedHelmet 4K PBR+IBL)",
+            "value": world * args.steps * npix / 1e6 / elapsed,
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"DamagedHelmet {W}x{H} single frame, {args.skybox_size}^2 skybox cube, irradiance 32^2, prefilter 128^2 x5, LUT 512^2, synthetic 4096x2048 HDR"
+                                   + f"; step i renders frame i of a 1-degree-per-frame camera orbit that starts at the reference's default view, frame f on rank f mod {world}",
+                       "covered_fraction": c, "triangles": stats.setup_triangles, "parallelism": "replicas only" if world == 1 else f"frame-sharded x{world}"},
+            "kernel_ms": {"resolve": resolve_ms, "vertex+setup+raster": geo_ms.value / max(frames.value, 1), "gpu_frame": tot_ms.value / max(frames.value, 1)},
+            "roofline": {"bound": "hbm", "kernel": "resolve_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": resolve_bytes},
+        }
+
+    if rank == 0 and not args.no_prefilter:
+        # second headline figure: the IBL GGX prefilter at 2048^2 x 10 mips x 1024 samples (single GPU here)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, args.prefilter_size, args.prefilter_mips, 1024, 0, 1))   # allocate + warm
+        torch.cuda.synchronize(dev)
+        ev0.record(stream)
+        pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, args.prefilter_size, args.prefilter_mips, 1024, 0, 1))
+        ev1.record(stream)
+        torch.cuda.synchronize(dev)
+        ms = ev0.elapsed_time(ev1)
+        texels = sum(6 * max(1, args.prefilter_size >> m) ** 2 for m in range(args.prefilter_mips))
+        result["ibl_prefilter"] = {"ms": ms, "config": f"{args.prefilter_size}^2 cube, {args.prefilter_mips} mips, 1024 samples/texel", "n_gpus": 1,
+                                   "algorithmic_tflops": texels * 1024 * 110 / (ms * 1e-3) / 1e12, "fp32_peak_tflops": 157.3}
+        # restore the frame's prefilter map
+        pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, r.prefilter_size, r.prefilter_mips, 1024, 0, 1))
+        torch.cuda.synchronize(dev)
+
+    if rank == 0 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(pkg, r, u_last, W, H)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    r.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,311 @@
+"""Known-answer tests that pin the CPU oracle.  The reference ships no tests or golden vectors
+(package.json:7), so every value here is derived by hand from the WGSL / TypeScript and computed
+in the test independently of the oracle's code."""
+import ctypes as C
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HELMET = os.path.join(ROOT, "assets", "DamagedHelmet")
+
+
+def test_radical_inverse():
+    # prefiltermap.wgsl:32-39
+    lib = ob.load()
+    assert lib.orc_radical_inverse(1) == 0.5
+    assert lib.orc_radical_inverse(2) == 0.25
+    assert lib.orc_radical_inverse(3) == 0.75
+    assert lib.orc_radical_inverse(1023) == 1023.0 / 1024.0
+    assert lib.orc_radical_inverse(0) == 0.0
+
+
+def test_irradiance_trip_counts():
+    # irradiancemap.wgsl:75-76 with f32 loop counters: 252 x 63 = 15876 taps
+    lib = ob.load()
+    a, b = C.c_int(), C.c_int()
+    lib.orc_irradiance_trip_counts(C.byref(a), C.byref(b))
+    assert (a.value, b.value) == (252, 63)
+    phi, n = np.float32(0), 0
+    while phi < np.float32(2.0) * np.float32(3.14159265359):
+        phi = np.float32(phi + np.float32(0.025)); n += 1
+    assert n == 252
+
+
+def test_f16_conversion_matches_ieee():
+    lib = ob.load()
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.normal(0, 1, 2000), rng.normal(0, 1e-6, 500), rng.normal(0, 7e4, 500),
+                           [0.0, -0.0, 1.0, 65504.0, 65520.0, 1e-8, 6e-8, np.inf, -np.inf]]).astype(np.float32)
+    for v in vals:
+        want = np.float32(v).astype(np.float16).view(np.uint16)
+        assert lib.orc_f32_to_f16(float(v)) == int(want), v
+    assert math.isnan(lib.orc_f16_to_f32(lib.orc_f32_to_f16(float("nan"))))
+    for h in [0, 1, 0x03ff, 0x0400, 0x3c00, 0x7bff, 0x8001, 0xfbff]:
+        assert lib.orc_f16_to_f32(h) == float(np.uint16(h).view(np.float16))
+
+
+def _coord_hdr(w, h):
+    hdr = np.zeros((h, w, 4), dtype=np.float32)
+    hdr[..., 0] = np.arange(w, dtype=np.float32)[None, :]
+    hdr[..., 1] = np.arange(h, dtype=np.float32)[:, None]
+    hdr[..., 3] = 1.0
+    return hdr.reshape(-1)
+
+
+FACES = [((1, 0, 0), (0, 1, 0), (0, 0, -1)), ((-1, 0, 0), (0, 1, 0), (0, 0, 1)), ((0, -1, 0), (0, 0, 1), (1, 0, 0)),
+         ((0, 1, 0), (0, 0, -1), (1, 0, 0)), ((0, 0, 1), (0, 1, 0), (1, 0, 0)), ((0, 0, -1), (0, 1, 0), (-1, 0, 0))]   # equirectangular.wgsl:20-57
+
+
+def test_equirect_face_table_and_pixel_choice():
+    """equirectangular.wgsl:60-69: corner texel gid=(0,0) of each face looks along
+    forward - right - up, and the source pixel is the truncated (atan2, asin) * invAtan + 0.5."""
+    w, h, size = 64, 32, 4
+    cube = ob.equirect_to_cube(_coord_hdr(w, h), w, h, size)
+    for face, (fwd, up, right) in enumerate(FACES):
+        for gy in range(size):
+            for gx in range(size):
+                cu = np.float32(gx) / np.float32(size) * np.float32(2) - np.float32(1)
+                cv = np.float32(gy) / np.float32(size) * np.float32(2) - np.float32(1)
+                d = np.array(fwd, np.float32) + np.array(right, np.float32) * cu + np.array(up, np.float32) * cv
+                d = d / np.float32(math.sqrt(float(np.dot(d.astype(np.float64), d.astype(np.float64)))))
+                u = np.float32(math.atan2(d[2], d[0])) * np.float32(0.1591) + np.float32(0.5)
+                v = np.float32(math.asin(min(1.0, max(-1.0, float(d[1]))))) * np.float32(0.3183) + np.float32(0.5)
+                # allow the neighbouring texel when the coordinate sits within rounding of a boundary
+                px, py = float(u) * w, float(v) * h
+                got = cube[face, gy, gx]
+                assert abs(got[0] - math.floor(px)) <= (1 if abs(px - round(px)) < 1e-3 else 0), (face, gx, gy)
+                assert abs(got[1] - math.floor(py)) <= (1 if abs(py - round(py)) < 1e-3 else 0), (face, gx, gy)
+    # gid = (0, 0): direction forward - right - up, e.g. +X face looks along (1, -1, 1) / sqrt(3)
+    d = np.array([1.0, -1.0, 1.0]) / math.sqrt(3)
+    u = math.atan2(d[2], d[0]) * 0.1591 + 0.5
+    v = math.asin(d[1]) * 0.3183 + 0.5
+    assert tuple(cube[0, 0, 0, :2]) == (math.floor(u * w), math.floor(v * h))
+
+
+def test_prefilter_roughness_zero_is_nearest_texel():
+    # prefiltermap.wgsl:131-168 with roughness 0: H = N = L, weight 1, mip 0 -> the equirect texel itself
+    pkg_hdr = np.random.default_rng(3).uniform(0.1, 4.0, size=(64 * 128 * 4)).astype(np.float32)
+    w, h, size = 128, 64, 8
+    chain, levels = ob.mip_chain_rgba32f(pkg_hdr, w, h)
+    pre = ob.prefilter_level(chain, w, h, levels, size, 0.0)
+    sky = ob.equirect_to_cube(pkg_hdr, w, h, size)
+    np.testing.assert_allclose(pre[..., :3], sky[..., :3], rtol=3e-5)
+    assert (pre[..., 3] == 1.0).all()
+
+
+def test_prefilter_constant_environment_is_constant():
+    w, h, size = 2048, 1024, 4
+    hdr = np.tile(np.array([0.5, 1.5, 2.5, 1.0], np.float32), w * h)
+    chain, levels = ob.mip_chain_rgba32f(hdr, w, h)
+    assert levels == 12
+    for rough in (0.25, 1.0):
+        pre = ob.prefilter_level(chain, w, h, levels, size, rough)
+        np.testing.assert_allclose(pre[..., :3], np.broadcast_to([0.5, 1.5, 2.5], pre[..., :3].shape), rtol=2e-5)
+
+
+def test_irradiance_constant_environment():
+    # irradiancemap.wgsl:75-88: PI * L * sum(cos t sin t) / N over the 252 x 63 grid
+    w, h, size = 64, 32, 2
+    hdr = np.tile(np.array([2.0, 1.0, 0.5, 1.0], np.float32), w * h)
+    irr = ob.irradiance(hdr, w, h, size)
+    s, theta = 0.0, np.float32(0)
+    thetas = []
+    while theta < np.float32(0.5) * np.float32(3.14159265359):
+        thetas.append(float(theta)); theta = np.float32(theta + np.float32(0.025))
+    s = sum(math.cos(t) * math.sin(t) for t in thetas) * 252
+    want = 3.14159265359 * s / (252 * 63)
+    np.testing.assert_allclose(irr[..., 0], 2.0 * want, rtol=1e-4)
+    np.testing.assert_allclose(irr[..., 2], 0.5 * want, rtol=1e-4)
+
+
+def test_brdf_lut_quirks():
+    """brdf.wgsl:67-106: column 0 (NdotV = 0) is 0/0 = NaN; row y holds roughness (size-y)/(size-1);
+    the last row/column entry is finite with A + B <= 1."""
+    size = 64
+    f32, f16 = ob.brdf_lut(size)
+    assert np.isnan(f32[:, 0, 0]).all() and np.isnan(f32[:, 0, 1]).all()
+    assert np.isfinite(f32[:, 1:, :2]).all()
+    a, b = f32[size - 1, size - 1, 0], f32[size - 1, size - 1, 1]
+    assert 0.9 < a + b <= 1.0 + 1e-6
+    assert (f32[..., 2] == 0).all() and (f32[..., 3] == 1).all()
+    # independent evaluation of one entry in f64 following the WGSL
+    x, y = 40, 20
+    ndv, rough = x / (size - 1), (size - y) / (size - 1)
+    V = np.array([math.sqrt(1 - ndv * ndv), 0.0, ndv])
+    A = B = 0.0
+    for i in range(1024):
+        xi_y = int(format(i, "032b")[::-1], 2) / 2 ** 32
+        phi = 2 * 3.14159265359 * i / 1024
+        a_ = rough * rough
+        ct = math.sqrt((1 - xi_y) / (1 + (a_ * a_ - 1) * xi_y)); st = math.sqrt(1 - ct * ct)
+        H = np.array([math.sin(phi) * st, -math.cos(phi) * st, ct])   # tangent (0,-1,0), bitangent (1,0,0) for N = +Z
+        L = 2 * V.dot(H) * H - V; L /= np.linalg.norm(L)
+        if L[2] > 0:
+            k = rough * rough / 2
+            G = (ndv / (ndv * (1 - k) + k)) * (L[2] / (L[2] * (1 - k) + k))
+            gv = G * max(V.dot(H), 0) / (max(H[2], 0) * ndv)
+            fc = (1 - max(V.dot(H), 0)) ** 5
+            A += (1 - fc) * gv; B += fc * gv
+    np.testing.assert_allclose(f32[y, x, :2], [A / 1024, B / 1024], rtol=2e-4)
+    assert (f16.view(np.float16).astype(np.float32)[y, x, :2] == f32[y, x, :2].astype(np.float16).astype(np.float32)).all()
+
+
+def test_mips_are_box_filters():
+    # mipmap.wgsl:23-26: one bilinear tap at the destination texel centre = 2x2 mean
+    rng = np.random.default_rng(5)
+    w, h = 8, 4
+    data = rng.uniform(0, 10, size=(h, w, 4)).astype(np.float32)
+    chain, levels = ob.mip_chain_rgba32f(data, w, h)
+    assert levels == 4      # utils.ts:20-24: 1 + floor(log2(8))
+    l1 = ob.chain_level(chain, w, h, 1)
+    want = data.reshape(h // 2, 2, w // 2, 2, 4).mean(axis=(1, 3))
+    np.testing.assert_allclose(l1, want, rtol=1e-6)
+    assert ob.chain_level(chain, w, h, 3).shape == (1, 1, 4)   # 8x4 -> 4x2 -> 2x1 -> 1x1
+    img = rng.integers(0, 256, size=(4, 4, 4), dtype=np.uint8); img[..., 3] = 255
+    c8, lv = ob.mip_chain_rgba8(img, False)
+    m = ob.chain_level(c8, 4, 4, 1)
+    want8 = np.rint(img.astype(np.float32).reshape(2, 2, 2, 2, 4).mean(axis=(1, 3)))
+    assert np.abs(m.astype(np.int32) - want8.astype(np.int32)).max() <= 1
+    cs, _ = ob.mip_chain_rgba8(img, True)   # sRGB: averaged in linear light, darker than the byte mean never brighter than max
+    ms = ob.chain_level(cs, 4, 4, 1)
+    assert (ms[..., :3] >= m[..., :3] - 1).all()   # linear-light average of an sRGB image is >= the encoded-value average
+
+
+def _helmet():
+    with open(os.path.join(HELMET, "DamagedHelmet.gltf")) as f:
+        g = json.load(f)
+    raw = open(os.path.join(HELMET, "DamagedHelmet.bin"), "rb").read()
+    return g, raw
+
+
+def test_helmet_asset_statistics():
+    # DamagedHelmet.gltf:6,18: 46356 indices = 15452 triangles, 14556 vertices; 10 triangles have a zero UV determinant
+    g, raw = _helmet()
+    idx = np.frombuffer(raw, np.uint16, 46356, 0).reshape(-1, 3)
+    pos = np.frombuffer(raw, np.float32, 14556 * 3, 92712).reshape(-1, 3)
+    uv = np.frombuffer(raw, np.float32, 14556 * 2, 442056).reshape(-1, 2)
+    assert idx.shape[0] == 15452 and idx.max() == 14555
+    np.testing.assert_allclose(pos.max(0), g["accessors"][1]["max"], rtol=1e-6)
+    np.testing.assert_allclose(pos.min(0), g["accessors"][1]["min"], rtol=1e-6)
+    assert uv[:, 1].min() > 1.0 and uv[:, 1].max() < 2.0      # only "repeat" addressing renders this mesh
+    e1, e2 = uv[idx[:, 1]] - uv[idx[:, 0]], uv[idx[:, 2]] - uv[idx[:, 0]]
+    det = e1[:, 0] * e2[:, 1] - e1[:, 1] * e2[:, 0]
+    assert int((det == 0).sum()) == 10
+    assert int((det < 0).sum()) == 7659
+
+
+def test_matrix_conventions():
+    lib = ob.load()
+    m = np.zeros(16, np.float32)
+    lib.orc_mat4_perspective(math.radians(45.0), 16 / 9, 1.0, 100.0, ob.ptr(m))
+    f = 1 / math.tan(math.radians(22.5))
+    np.testing.assert_allclose(m[0], f / (16 / 9), rtol=1e-6)
+    np.testing.assert_allclose(m[5], 2.41421356, rtol=1e-6)
+    assert m[11] == -1 and m[15] == 0
+    np.testing.assert_allclose([m[10], m[14]], [100 / (1 - 100), 100 / (1 - 100)], rtol=1e-6)   # z in [0,1]: near -> 0, far -> 1
+    eye, tgt, up = np.array([0, 0, 5], np.float32), np.zeros(3, np.float32), np.array([0, 1, 0], np.float32)
+    lib.orc_mat4_look_at(ob.ptr(eye), ob.ptr(tgt), ob.ptr(up), ob.ptr(m))
+    want = np.eye(4, dtype=np.float32); want[3, 2] = -5     # column-major: translation in elements 12..14
+    np.testing.assert_array_equal(m.reshape(4, 4), want)
+    q = np.array([0.7071068286895752, 0, 0, 0.7071068286895752], np.float32)   # DamagedHelmet.gltf:162-167
+    lib.orc_node_matrix(None, None, ob.ptr(q), None, ob.ptr(m))
+    rx = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1]], np.float32)   # +90 degrees about X, columns
+    np.testing.assert_allclose(m.reshape(4, 4), rx, atol=1e-6)
+    inv = np.zeros(16, np.float32)
+    a = np.random.default_rng(2).normal(size=16).astype(np.float32)
+    assert lib.orc_mat4_inverse(ob.ptr(a), ob.ptr(inv)) == 0
+    prod = np.zeros(16, np.float32)
+    lib.orc_mat4_mul(ob.ptr(a), ob.ptr(inv), ob.ptr(prod))
+    np.testing.assert_allclose(prod.reshape(4, 4), np.eye(4), atol=1e-4)
+
+
+# ---- rasteriser known answers on hand-made meshes ----
+def _tiny_scene(verts, indices):
+    sc = ob.Scene()
+    sc.verts = ob.ptr(verts); sc.n_verts = verts.size // 8
+    sc.indices = ob.ptr(indices); sc.n_indices = indices.size
+    sc.n_instances = 1
+    return sc
+
+
+def _identity_uniforms():
+    u = ob.FrameUniforms()
+    eye = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    for name in ("model", "normal", "view", "projection", "inv_view_proj"):
+        getattr(u, name)[:] = eye
+    return u
+
+
+def _raster(verts_xyz, tris, W, H):
+    lib = ob.load()
+    v = np.zeros((len(verts_xyz), 8), np.float32)
+    v[:, :3] = verts_xyz
+    v[:, 7] = 1
+    idx = np.asarray(tris, np.uint16).reshape(-1)
+    sc = _tiny_scene(v, idx)
+    u = _identity_uniforms()
+    vis = np.zeros((H, W), np.uint32); depth = np.zeros((H, W), np.float32)
+    lib.orc_raster(C.byref(sc), C.byref(u), W, H, 0, H, ob.ptr(vis), ob.ptr(depth))
+    return vis, depth
+
+
+def test_raster_fill_rule_partitions_a_quad():
+    """Two triangles sharing a diagonal cover every pixel of the quad exactly once (top-left rule),
+    and the viewport maps NDC y = +1 to row 0."""
+    W, H = 16, 8
+    quad = [(-1, -1, 0.5), (1, -1, 0.5), (1, 1, 0.5), (-1, 1, 0.5)]
+    vis, depth = _raster(quad, [(0, 1, 2), (0, 2, 3)], W, H)   # counter-clockwise in NDC = front-facing
+    assert (vis > 0).all()
+    assert set(np.unique(vis)) == {1, 2}
+    assert vis[H - 1, W - 1] == 1 and vis[0, 0] == 2          # triangle (0,1,2) holds the bottom-right corner
+    assert (depth == 0.5).all()
+    # a half-pixel-aligned inner quad: pixel centres exactly on the left/top edges are inside, on the right/bottom edges outside
+    x0, x1, y0, y1 = 4.5, 10.5, 2.5, 5.5
+    def ndc(px, py):
+        return (px / W * 2 - 1, 1 - py / H * 2, 0.25)
+    q2 = [ndc(x0, y1), ndc(x1, y1), ndc(x1, y0), ndc(x0, y0)]
+    vis, _ = _raster(q2, [(0, 1, 2), (0, 2, 3)], W, H)
+    cov = vis > 0
+    assert cov[2:5, 4:10].all() and cov.sum() == 3 * 6
+
+
+def test_raster_culls_back_faces_and_resolves_depth():
+    W, H = 8, 8
+    quad = [(-1, -1, 0.5), (1, -1, 0.5), (1, 1, 0.5), (-1, 1, 0.5)]
+    vis, _ = _raster(quad, [(0, 2, 1), (0, 3, 2)], W, H)      # clockwise: culled (cullMode "back", renderer.ts:471)
+    assert (vis == 0).all()
+    near = [(x, y, 0.2) for x, y, _ in quad]
+    vis, depth = _raster(quad + near, [(0, 1, 2), (0, 2, 3), (4, 5, 6), (4, 6, 7)], W, H)
+    assert set(np.unique(vis)) == {3, 4} and (depth == np.float32(0.2)).all()      # depthCompare "less"
+    vis, _ = _raster(quad + quad, [(0, 1, 2), (0, 2, 3), (4, 5, 6), (4, 6, 7)], W, H)
+    assert set(np.unique(vis)) == {1, 2}                       # equal depth: the earlier draw stays
+    behind = [(x, y, 1.5) for x, y, _ in quad]                 # beyond the far plane: clipped away
+    vis, _ = _raster(behind, [(0, 1, 2), (0, 2, 3)], W, H)
+    assert (vis == 0).all()
+
+
+def test_raster_clips_against_the_near_plane():
+    """A triangle with one vertex behind the eye (w < 0) is clipped, not dropped: the part in front
+    of the near plane still covers pixels."""
+    lib = ob.load()
+    W, H = 32, 32
+    proj = np.zeros(16, np.float32)
+    lib.orc_mat4_perspective(math.radians(90.0), 1.0, 1.0, 100.0, ob.ptr(proj))
+    v = np.zeros((3, 8), np.float32)
+    # The third vertex is behind the camera at the origin; the edges cross the near plane at
+    # NDC (-1.2, 0.6) and (1.2, 0.6), above the two visible vertices, so (0, 1, 2) stays counter-clockwise.
+    v[:, :3] = [(-2, -1, -3), (2, -1, -3), (0, 3.0, 2.0)]
+    idx = np.array([0, 1, 2], np.uint16)
+    sc = _tiny_scene(v, idx)
+    u = _identity_uniforms()
+    u.projection[:] = [float(x) for x in proj]
+    vis = np.zeros((H, W), np.uint32); depth = np.zeros((H, W), np.float32)
+    lib.orc_raster(C.byref(sc), C.byref(u), W, H, 0, H, ob.ptr(vis), ob.ptr(depth))
+    assert (vis > 0).sum() > 50
+    assert depth[vis > 0].min() >= 0.0 and depth[vis > 0].max() < 1.0
