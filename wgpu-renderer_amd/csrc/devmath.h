@@ -25,10 +25,20 @@ PBR_DEV bool any_nan(V3 a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
 PBR_DEV float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 PBR_DEV float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
 
-// Arithmetic that must give the same bits as a host evaluation: no FMA contraction.
-PBR_DEV float mul_rn(float a, float b) { return __fmul_rn(a, b); }
-PBR_DEV float add_rn(float a, float b) { return __fadd_rn(a, b); }
-PBR_DEV float sub_rn(float a, float b) { return __fsub_rn(a, b); }
+// Arithmetic that must give the same bits as a host evaluation: one IEEE operation each, never
+// contracted into an FMA (HIP's __fmul_rn / __fadd_rn are plain operators and do get contracted).
+PBR_DEV float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+PBR_DEV float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+PBR_DEV float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
 PBR_DEV float div_rn(float a, float b) { return __fdiv_rn(a, b); }
 
 // o = a * b for column-major 4x4 matrices, each element ((p0 + p1) + p2) + p3.
