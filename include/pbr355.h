@@ -138,6 +138,9 @@ int pbr_draw_frame_device(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w,
 /* Stage outputs for verification: clip[n][4], world[n][3], normal[n][3] of vs_main
  * (shader.wgsl:37-47) for n = instance_count*n_verts, and the f32 depth buffer of the last frame. */
 int pbr_debug_vertex_stage(PbrContext* ctx, const PbrFrameUniforms* u, float* clip, float* world, float* normal);
+/* The depth buffer normally lives only in on-chip memory during rasterisation; enable capture to
+ * have the following frames also write it to device memory so pbr_debug_depth can return it. */
+int pbr_debug_capture_depth(PbrContext* ctx, int32_t enable);
 int pbr_debug_depth(PbrContext* ctx, float* depth_out, size_t n_floats);
 
 /* ---- kernel timing for benchmarks: HIP events recorded on the context's stream around the

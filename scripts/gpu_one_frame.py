@@ -1,0 +1,14 @@
+"""Renders a few 4K frames (for profilers): python scripts/gpu_one_frame.py [distance] [frames]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+pkg = entry.load_package()
+dist = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+r = pkg.Renderer(width=3840, height=2160, skybox_size=1024)
+r.init()
+r.camera.update_camera_distance((5.0 - dist) * 100.0, 0.0)
+for _ in range(frames):
+    _, st = r.draw_frame(want_stats=True)
+print("resolve ms", st.ms_resolve, "raster ms", st.ms_raster, "covered", st.covered_pixels)

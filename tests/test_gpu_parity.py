@@ -102,6 +102,7 @@ def test_vertex_stage_is_bit_exact(small):
 
 def test_default_view_matches_oracle(small):
     small.renderer.camera = small.pkg.Camera()
+    pu._pkg()._lib.check(small.renderer._ctx, small.renderer._lib.pbr_debug_capture_depth(small.renderer._ctx, 1))
     rgba, vis = small.render_gpu()
     orgba, ovis = small.render_oracle()
     assert (vis == ovis).all()                                        # integer work: bit-exact
@@ -112,6 +113,7 @@ def test_default_view_matches_oracle(small):
     pu._pkg()._lib.check(small.renderer._ctx, small.renderer._lib.pbr_debug_depth(small.renderer._ctx, ob.ptr(depth), depth.size))
     _, odepth = small.oracle.raster(small.uniforms(), small.width, small.height)
     assert (depth.view(np.uint32) == odepth.view(np.uint32)).all()
+    pu._pkg()._lib.check(small.renderer._ctx, small.renderer._lib.pbr_debug_capture_depth(small.renderer._ctx, 0))
 
 
 @pytest.mark.parametrize("moves", [

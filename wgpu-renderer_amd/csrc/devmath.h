@@ -21,6 +21,16 @@ PBR_DEV V3 normalize(V3 a) {
   float l = sqrtf(dot(a, a));
   return v3(a.x / l, a.y / l, a.z / l);
 }
+// Hardware approximations (about 1 ulp): used where the result only feeds 8-bit colour, never an
+// integer decision.  rsq(0) = +inf, so a zero vector still normalises to NaN (0 * inf).
+PBR_DEV float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+PBR_DEV float rsq_fast(float x) { return __builtin_amdgcn_rsqf(x); }
+PBR_DEV float log2_fast(float x) { return __builtin_amdgcn_logf(x); }
+PBR_DEV float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+PBR_DEV V3 normalize_fast(V3 a) {
+  const float r = rsq_fast(dot(a, a));
+  return v3(a.x * r, a.y * r, a.z * r);
+}
 PBR_DEV bool any_nan(V3 a) { return isnan(a.x) || isnan(a.y) || isnan(a.z); }
 PBR_DEV float clamp01(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 PBR_DEV float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }

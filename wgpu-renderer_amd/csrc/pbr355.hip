@@ -156,6 +156,7 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
     HIP_TRY(c, hipMalloc(&c->d_tile_count, sizeof(uint32_t) * n_tiles));
     HIP_TRY(c, hipMalloc(&c->d_tile_offset, sizeof(uint32_t) * n_tiles));
     HIP_TRY(c, hipMalloc(&c->d_tile_cursor, sizeof(uint32_t) * n_tiles));
+    HIP_TRY(c, hipMemset(c->d_tile_count, 0, sizeof(uint32_t) * n_tiles));   // kept clear from frame to frame by the raster kernel
     c->tile_cap = n_tiles; grew = true;
   }
   const size_t npix = (size_t)W * rows;
@@ -204,6 +205,7 @@ static int check_sticky(PbrContext* c) {
   if (c->h_counters && c->h_counters[2]) {
     uint32_t code = c->h_counters[2];
     c->h_counters[2] = 0;
+    (void)hipMemset(&c->d_counters[2], 0, sizeof(uint32_t));
     return fail(c, PBR_E_STATE, code == 1 ? "triangle setup buffer overflow" : "tile bin list overflow");
   }
   return PBR_OK;
@@ -257,7 +259,8 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
                        c->d_bin_list, (uint32_t)c->bin_cap, c->d_counters, c->n_indices / 3, c->n_instances, tiles_x * tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
-  launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_tile_offset, c->d_bin_list, vis, c->d_depth, tiles_x, tiles_y);
+  launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_tile_offset, c->d_bin_list, vis, c->capture_depth ? c->d_depth : nullptr, c->d_counters, tiles_x,
+                tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
   if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames + 1], s));
 
@@ -266,7 +269,14 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   for (int i = 0; i < 5; ++i) in.tex[i] = c->tex[i];
   in.irr = c->irr; in.pre = c->pre; in.sky = c->sky;
   in.lut = c->d_lut; in.lut_size = c->lut_size;
-  launch_resolve(s, dp, in, pr->d_srgb_lut, vis, static_cast<uint8_t*>(d_rgba8), &c->d_counters[3], W, rows);
+  // the specialised resolve covers the reference's default sampler on power-of-two textures
+  static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
+  bool fast = u->sampler_index == 15u;
+  for (int i = 0; i < 5; ++i) fast = fast && c->tex[i].srgb == kFormatSrgb[i];
+  for (int i = 0; i < 5; ++i)
+    fast = fast && (c->tex[i].w & (c->tex[i].w - 1)) == 0 && (c->tex[i].h & (c->tex[i].h - 1)) == 0 && c->tex[i].w == c->tex[0].w &&
+           c->tex[i].h == c->tex[0].h && c->tex[i].levels == c->tex[0].levels;
+  launch_resolve(s, dp, in, pr->d_srgb_lut, vis, static_cast<uint8_t*>(d_rgba8), W, rows, fast);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   if (prof) { HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames + 2], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
@@ -274,15 +284,17 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   ++pr->frames_drawn;
 
   if (timed) {
-    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemsetAsync(&c->d_counters[3], 0, sizeof(uint32_t), s));
+    launch_count_covered(s, vis, (size_t)W * rows, &c->d_counters[3]);
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     (void)hipEventElapsedTime(&stats->ms_vertex, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&stats->ms_setup, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&stats->ms_raster, c->ev[2], c->ev[3]);
     (void)hipEventElapsedTime(&stats->ms_resolve, c->ev[3], c->ev[4]);
     (void)hipEventElapsedTime(&stats->ms_total, c->ev[0], c->ev[4]);
-    stats->setup_triangles = c->h_counters[0];
-    stats->binned_refs = c->h_counters[1];
+    stats->setup_triangles = c->h_counters[4];
+    stats->binned_refs = c->h_counters[5];
     stats->covered_pixels = c->h_counters[3];
     stats->reserved = 0;
     return check_sticky(c);
@@ -315,10 +327,10 @@ int pbr_create(int device_ordinal, PbrContext** ctx_out) {
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   c->stream = c->own_stream;
   for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&c->d_counters, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMemset(c->d_counters, 0, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
-  if ((e = hipHostMalloc(&c->h_counters, 4 * sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
-  std::memset(c->h_counters, 0, 4 * sizeof(uint32_t));
+  if ((e = hipMalloc(&c->d_counters, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
+  if ((e = hipHostMalloc(&c->h_counters, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
+  std::memset(c->h_counters, 0, 8 * sizeof(uint32_t));
   ParamRing& ring = box->priv.ring;
   if ((e = hipHostMalloc(&ring.host, PARAM_SLOTS * sizeof(FrameParams))) != hipSuccess) return bail("hipHostMalloc", e);
   if ((e = hipMalloc(&ring.dev, PARAM_SLOTS * sizeof(FrameParams))) != hipSuccess) return bail("hipMalloc", e);
@@ -371,7 +383,7 @@ int pbr_synchronize(PbrContext* c) {
   if (!c) return PBR_E_ARG;
   DeviceGuard guard(c->device);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return check_sticky(c);
 }
 
@@ -667,7 +679,7 @@ int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t 
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(rgba8_out, c->d_color, npix * 4, hipMemcpyDeviceToHost));
   if (vis_out) HIP_TRY(c, hipMemcpy(vis_out, c->d_vis, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return check_sticky(c);
 }
 
@@ -698,8 +710,15 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   return PBR_OK;
 }
 
+int pbr_debug_capture_depth(PbrContext* c, int32_t enable) {
+  if (!c) return PBR_E_ARG;
+  c->capture_depth = enable != 0;
+  return PBR_OK;
+}
+
 int pbr_debug_depth(PbrContext* c, float* depth_out, size_t n_floats) {
   if (!c || !depth_out) return PBR_E_ARG;
+  if (!c->capture_depth) return fail(c, PBR_E_STATE, "depth capture is off; call pbr_debug_capture_depth(ctx, 1) before drawing");
   const size_t n = (size_t)c->last_w * c->last_rows;
   if (!c->d_depth || n == 0) return fail(c, PBR_E_STATE, "no frame drawn yet");
   if (n_floats < n) return fail(c, PBR_E_ARG, "depth buffer needs %zu floats", n);

@@ -101,7 +101,8 @@ struct PbrContext {
   SetupTri* d_setup = nullptr;    size_t setup_cap = 0;
   uint32_t* d_tile_count = nullptr; uint32_t* d_tile_offset = nullptr; uint32_t* d_tile_cursor = nullptr; size_t tile_cap = 0;
   uint32_t* d_bin_list = nullptr; size_t bin_cap = 0;
-  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels
+  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [4] [5] last frame's [0] [1]
+  bool capture_depth = false;
   uint32_t* h_counters = nullptr; // pinned mirror
   uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0;
   int32_t last_w = 0, last_rows = 0;
@@ -129,8 +130,8 @@ void launch_vertex_stage(hipStream_t s, const FrameParams* p, const float* vsoa,
 void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* bin_list,
                           uint32_t bin_cap, uint32_t* counters, int n_tris, int n_instances, int n_tiles);
-void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, const uint32_t* tile_count, const uint32_t* tile_offset,
-                   const uint32_t* bin_list, uint32_t* vis, float* depth, int tiles_x, int tiles_y);
+void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* tile_offset,
+                   const uint32_t* bin_list, uint32_t* vis, float* depth, uint32_t* counters, int tiles_x, int tiles_y);
 struct ResolveInputs {
   const VertexOut* vout;
   const uint16_t* indices;
@@ -140,4 +141,5 @@ struct ResolveInputs {
   int32_t lut_size;
 };
 void launch_resolve(hipStream_t s, const FrameParams* p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    uint32_t* covered, int W, int rows);
+                    int W, int rows, bool fast);
+void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered);

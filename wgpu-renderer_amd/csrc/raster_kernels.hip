@@ -192,110 +192,164 @@ __global__ void __launch_bounds__(256) bin_fill_kernel(const FrameParams* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Tile rasteriser.  One 256-thread workgroup owns a 32x32 pixel tile; each thread owns a 2x2
-// quad and keeps its four depth / id pairs in registers, so the depth buffer never touches
-// memory during rasterisation.  The tile's bin is consumed in chunks of 256 triangles: every
-// thread fetches one triangle, tests it exactly against the tile, and the survivors are compacted
-// into an LDS-resident list with a wavefront ballot and prefix count; then all threads walk that
-// list (LDS broadcast reads) and test their pixels with 64-bit edge functions.
+// Tile rasteriser.  One 256-thread workgroup owns a 32x32 pixel tile whose depth / id buffer lives
+// in LDS as one 64-bit key per pixel (order-preserving depth bits in the high word, triangle id + 1
+// in the low word), so "nearest fragment, earliest triangle on ties" is a single ds_min_u64 and
+// the depth buffer never touches HBM.  Work is triangle-parallel: each wavefront takes 64 bin
+// entries at a time, one per lane, where the lane sets the triangle up against the tile (edge
+// functions at the tile origin, exact tile-overlap test, bounding box inside the tile); the
+// surviving lanes are then served one after the other — the lane's record is broadcast with
+// readlane and the 64 lanes sweep the triangle's bounding box as 8x8 pixel blocks.
 // ---------------------------------------------------------------------------------------------
-struct LdsTri {
-  long long e[3];      // edge functions at the tile's first pixel centre
-  int a[3], b[3];      // d e / d x, d e / d y per 1/256 pixel
-  float z0, dz1, dz2, inv_area;
-  uint32_t id;
-  uint32_t tl;         // bit k set: edge k is a top or left edge (covers pixels exactly on it)
-};
+PBR_DEV uint32_t depth_key(float z) {
+  const uint32_t b = __float_as_uint(z);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);   // unsigned order == float order
+}
+PBR_DEV float key_depth(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+PBR_DEV int bcast(int v, int src_lane) { return __builtin_amdgcn_readlane(v, src_lane); }
+PBR_DEV long long bcast64(long long v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), src_lane), hi = __builtin_amdgcn_readlane((int)(v >> 32), src_lane);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
 
 __global__ void __launch_bounds__(256) raster_kernel(const FrameParams* __restrict__ p, const SetupTri* __restrict__ setup,
-                                                     const uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_offset,
-                                                     const uint32_t* __restrict__ bin_list, uint32_t* __restrict__ vis, float* __restrict__ depth) {
-  __shared__ LdsTri s_tri[256];
-  __shared__ uint32_t s_wave_count[4];
+                                                     uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_offset,
+                                                     const uint32_t* __restrict__ bin_list, uint32_t* __restrict__ vis, float* __restrict__ depth,
+                                                     uint32_t* __restrict__ counters) {
+  __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
   const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px0 = blockIdx.x * PBR_TILE, py0 = p->y0 + blockIdx.y * PBR_TILE;   // tile origin in pixels
-  const int qx = (tid & 15) * 2, qy = (tid >> 4) * 2;                           // this thread's quad inside the tile
   const uint32_t n = tile_count[tile], base = tile_offset[tile];
-  const long long ox = (long long)px0 * 256 + 128, oy = (long long)py0 * 256 + 128;
   const int xmax = min(px0 + PBR_TILE, p->W) - 1, ymax = min(py0 + PBR_TILE, p->y1) - 1;
+  const unsigned long long clear_key = (unsigned long long)depth_key(1.0f) << 32;   // depth clear 1.0, no triangle
 
-  float zmin[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-  uint32_t best[4] = {0u, 0u, 0u, 0u};
+  if (tile == 0 && tid == 0) {   // hand the frame's counters to the statistics slots and re-arm them for the next frame
+    counters[4] = counters[0]; counters[5] = counters[1];
+    counters[0] = 0u; counters[1] = 0u;
+  }
 
-  for (uint32_t chunk = 0; chunk < n; chunk += 256) {
-    // phase 1: fetch, exact tile test, compact
-    bool keep = false;
-    LdsTri lt;
-    if (chunk + tid < n) {
-      const SetupTri t = setup[bin_list[base + chunk + tid]];
-      keep = true;
-      lt.tl = 0;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int ia = (k + 1) % 3, ib = (k + 2) % 3;
-        const int dx = t.X[ib] - t.X[ia], dy = t.Y[ib] - t.Y[ia];
-        lt.a[k] = -dy; lt.b[k] = dx;
-        lt.e[k] = (long long)dx * (oy - t.Y[ia]) - (long long)dy * (ox - t.X[ia]);
-        const bool tl = dy < 0 || (dy == 0 && dx > 0);
-        if (tl) lt.tl |= 1u << k;
-        // largest value of the edge function over the tile's pixel centres
-        const long long ex = lt.a[k] > 0 ? (long long)lt.a[k] * ((xmax - px0) * 256) : 0;
-        const long long ey = lt.b[k] > 0 ? (long long)lt.b[k] * ((ymax - py0) * 256) : 0;
-        const long long emax = lt.e[k] + ex + ey;
-        if (emax < 0 || (emax == 0 && !tl)) keep = false;
-      }
-      lt.z0 = t.z0; lt.dz1 = t.dz1; lt.dz2 = t.dz2; lt.inv_area = t.inv_area; lt.id = t.id;
-    }
-    const unsigned long long mask = __ballot(keep);
-    if (lane == 0) s_wave_count[wave] = (uint32_t)__popcll(mask);
+  if (n != 0u) {
+    for (int i = tid; i < PBR_TILE * PBR_TILE; i += 256) s_key[i] = clear_key;
     __syncthreads();
-    uint32_t wave_base = 0, m = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { if (w < wave) wave_base += s_wave_count[w]; m += s_wave_count[w]; }
-    if (keep) s_tri[wave_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = lt;
-    __syncthreads();
-
-    // phase 2: every thread walks the compacted list
-    for (uint32_t j = 0; j < m; ++j) {
-      const LdsTri& t = s_tri[j];
-      long long e[3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) e[k] = t.e[k] + (long long)t.a[k] * (qx * 256) + (long long)t.b[k] * (qy * 256);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int sx = s & 1, sy = s >> 1;
-        long long f[3];
-        bool in = true;
+    const long long ox = (long long)px0 * 256 + 128, oy = (long long)py0 * 256 + 128;
+    for (uint32_t chunk = 0; chunk < n; chunk += 256) {
+      // lane-parallel: fetch one triangle per lane and set it up against this tile.  Entry
+      // chunk + 4*lane + wave goes to this lane, so a short bin is still spread over all four waves.
+      bool keep = false;
+      long long e0 = 0, e1 = 0, e2 = 0;
+      int a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0, tl = 0, box = 0;
+      float z0 = 0, dz1 = 0, dz2 = 0, inv_area = 0;
+      uint32_t id = 0;
+      const uint32_t entry = chunk + 4u * lane + wave;
+      if (entry < n) {
+        const SetupTri t = setup[bin_list[base + entry]];
+        keep = true;
+        long long e[3]; int a[3], b[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          f[k] = e[k] + (sx ? (long long)t.a[k] * 256 : 0) + (sy ? (long long)t.b[k] * 256 : 0);
-          in = in && (f[k] > 0 || (f[k] == 0 && ((t.tl >> k) & 1u)));
+          const int ia = (k + 1) % 3, ib = (k + 2) % 3;
+          const int dx = t.X[ib] - t.X[ia], dy = t.Y[ib] - t.Y[ia];
+          a[k] = -dy; b[k] = dx;
+          e[k] = (long long)dx * (oy - t.Y[ia]) - (long long)dy * (ox - t.X[ia]);
+          const bool is_tl = dy < 0 || (dy == 0 && dx > 0);   // left edge, or top edge: pixels exactly on it are covered
+          if (is_tl) tl |= 1 << k;
+          // largest value of the edge function over the tile's pixel centres
+          const long long ex = a[k] > 0 ? (long long)a[k] * ((xmax - px0) * 256) : 0;
+          const long long ey = b[k] > 0 ? (long long)b[k] * ((ymax - py0) * 256) : 0;
+          const long long emax = e[k] + ex + ey;
+          if (emax < 0 || (emax == 0 && !is_tl)) keep = false;
         }
-        if (in) {
-          const float l1 = mul_rn((float)f[1], t.inv_area), l2 = mul_rn((float)f[2], t.inv_area);
-          const float z = add_rn(add_rn(t.z0, mul_rn(l1, t.dz1)), mul_rn(l2, t.dz2));
-          if (z < zmin[s] || (z == zmin[s] && best[s] != 0u && t.id + 1u < best[s])) { zmin[s] = z; best[s] = t.id + 1u; }
+        e0 = e[0]; e1 = e[1]; e2 = e[2]; a0 = a[0]; a1 = a[1]; a2 = a[2]; b0 = b[0]; b1 = b[1]; b2 = b[2];
+        z0 = t.z0; dz1 = t.dz1; dz2 = t.dz2; inv_area = t.inv_area; id = t.id;
+        // bounding box of the covered pixel centres, clamped to the tile
+        const int minX = min(t.X[0], min(t.X[1], t.X[2])), maxX = max(t.X[0], max(t.X[1], t.X[2]));
+        const int minY = min(t.Y[0], min(t.Y[1], t.Y[2])), maxY = max(t.Y[0], max(t.Y[1], t.Y[2]));
+        const int bx0 = max((minX - 128 + 255) >> 8, px0) - px0, bx1 = min((maxX - 128) >> 8, xmax) - px0;
+        const int by0 = max((minY - 128 + 255) >> 8, py0) - py0, by1 = min((maxY - 128) >> 8, ymax) - py0;
+        if (bx0 > bx1 || by0 > by1) keep = false;
+        box = bx0 | (bx1 << 8) | (by0 << 16) | (by1 << 24);
+        // 32-bit evaluation is exact when every edge value over the tile and both factors of the 24-bit multiplies fit
+        bool narrow = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const long long reach = (long long)(abs(a[k]) + abs(b[k])) * (PBR_TILE * 256);
+          const long long mag = e[k] < 0 ? -e[k] : e[k];
+          narrow = narrow && abs(a[k]) < (1 << 23) && abs(b[k]) < (1 << 23) && mag + reach < (1ll << 31) - 1;
+        }
+        if (narrow) tl |= 8;
+      }
+      unsigned long long todo = __ballot(keep);
+      const int lx = lane & 7, ly = lane >> 3;
+      while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long long E0 = bcast64(e0, src), E1 = bcast64(e1, src), E2 = bcast64(e2, src);
+        const int A0 = bcast(a0, src), A1 = bcast(a1, src), A2 = bcast(a2, src), B0 = bcast(b0, src), B1 = bcast(b1, src), B2 = bcast(b2, src);
+        const int TL = bcast(tl, src), BOX = bcast(box, src);
+        const float Z0 = __int_as_float(bcast(__float_as_int(z0), src)), DZ1 = __int_as_float(bcast(__float_as_int(dz1), src)),
+                    DZ2 = __int_as_float(bcast(__float_as_int(dz2), src)), IA = __int_as_float(bcast(__float_as_int(inv_area), src));
+        const uint32_t ID = (uint32_t)bcast((int)id, src) + 1u;
+        const int bx0 = BOX & 255, bx1 = (BOX >> 8) & 255, by0 = (BOX >> 16) & 255, by1 = (BOX >> 24) & 255;
+        const long long bias0 = (TL & 1) ? 0 : -1, bias1 = (TL & 2) ? 0 : -1, bias2 = (TL & 4) ? 0 : -1;   // e > 0, or e >= 0 on top-left edges
+        if (TL & 8) {
+          // common case: small on-screen triangle, 32-bit edge functions with 24-bit multiplies
+          const int e0n = (int)E0 + (int)bias0, e1n = (int)E1, e2n = (int)E2;
+          const int c1 = (int)bias1, c2 = (int)bias2;
+          for (int yy = by0; yy <= by1; yy += 8)
+            for (int xx = bx0; xx <= bx1; xx += 8) {
+              const int x = xx + lx, y = yy + ly;
+              if (x > bx1 || y > by1) continue;
+              const int xs = x * 256, ys = y * 256;
+              const int f0 = e0n + __mul24(A0, xs) + __mul24(B0, ys);
+              const int f1 = e1n + __mul24(A1, xs) + __mul24(B1, ys);
+              const int f2 = e2n + __mul24(A2, xs) + __mul24(B2, ys);
+              if ((f0 | (f1 + c1) | (f2 + c2)) < 0) continue;
+              const float l1 = mul_rn((float)f1, IA), l2 = mul_rn((float)f2, IA);
+              const float z = add_rn(add_rn(Z0, mul_rn(l1, DZ1)), mul_rn(l2, DZ2));
+              atomicMin(&s_key[y * PBR_TILE + x], ((unsigned long long)depth_key(z) << 32) | ID);
+            }
+        } else {
+          for (int yy = by0; yy <= by1; yy += 8)
+            for (int xx = bx0; xx <= bx1; xx += 8) {
+              const int x = xx + lx, y = yy + ly;
+              if (x > bx1 || y > by1) continue;
+              const long long f0 = E0 + (long long)A0 * (x * 256) + (long long)B0 * (y * 256);
+              const long long f1 = E1 + (long long)A1 * (x * 256) + (long long)B1 * (y * 256);
+              const long long f2 = E2 + (long long)A2 * (x * 256) + (long long)B2 * (y * 256);
+              if (((f0 + bias0) | (f1 + bias1) | (f2 + bias2)) < 0) continue;
+              const float l1 = mul_rn((float)f1, IA), l2 = mul_rn((float)f2, IA);
+              const float z = add_rn(add_rn(Z0, mul_rn(l1, DZ1)), mul_rn(l2, DZ2));
+              atomicMin(&s_key[y * PBR_TILE + x], ((unsigned long long)depth_key(z) << 32) | ID);
+            }
         }
       }
     }
     __syncthreads();
   }
+  if (tid == 0) tile_count[tile] = 0u;   // leave the bin counters clear for the next frame
 
-  const int rows_w = p->W;
+  // write the tile out: thread t holds pixels 4t .. 4t+3 of the row-major tile
+  const int ty = tid >> 3, tx = (tid & 7) * 4;
+  const int y = py0 + ty, x = px0 + tx;
+  if (y > ymax || x > xmax) return;
+  uint32_t ids[4] = {0u, 0u, 0u, 0u};
+  float zs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+  if (n != 0u) {
 #pragma unroll
-  for (int sy = 0; sy < 2; ++sy) {
-    const int y = py0 + qy + sy;
-    if (y > ymax) continue;
-    const int x = px0 + qx;
-    const size_t o = (size_t)(y - p->y0) * rows_w + x;
-    if (x + 1 <= xmax && (o & 1) == 0) {
-      *reinterpret_cast<uint2*>(vis + o) = make_uint2(best[sy * 2], best[sy * 2 + 1]);
-      if (depth) *reinterpret_cast<float2*>(depth + o) = make_float2(zmin[sy * 2], zmin[sy * 2 + 1]);
-    } else {
-      if (x <= xmax) { vis[o] = best[sy * 2]; if (depth) depth[o] = zmin[sy * 2]; }
-      if (x + 1 <= xmax) { vis[o + 1] = best[sy * 2 + 1]; if (depth) depth[o + 1] = zmin[sy * 2 + 1]; }
+    for (int k = 0; k < 4; ++k) {
+      const unsigned long long key = s_key[ty * PBR_TILE + tx + k];
+      ids[k] = (uint32_t)key; zs[k] = key_depth((uint32_t)(key >> 32));
     }
+  }
+  const size_t o = (size_t)(y - p->y0) * p->W + x;
+  if (x + 3 <= xmax && (o & 3) == 0) {
+    *reinterpret_cast<uint4*>(vis + o) = make_uint4(ids[0], ids[1], ids[2], ids[3]);
+    if (depth) *reinterpret_cast<float4*>(depth + o) = make_float4(zs[0], zs[1], zs[2], zs[3]);
+  } else {
+    for (int k = 0; k < 4; ++k)
+      if (x + k <= xmax) { vis[o + k] = ids[k]; if (depth) depth[o + k] = zs[k]; }
   }
 }
 
@@ -310,8 +364,7 @@ void launch_vertex_stage(hipStream_t s, const FrameParams* p, const float* vsoa,
 void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* bin_list,
                           uint32_t bin_cap, uint32_t* counters, int n_tris, int n_instances, int n_tiles) {
-  (void)hipMemsetAsync(tile_count, 0, sizeof(uint32_t) * (size_t)n_tiles, s);
-  (void)hipMemsetAsync(counters, 0, sizeof(uint32_t) * 4, s);
+  // tile_count and the counters are zero on entry: the raster kernel of the previous frame clears them
   dim3 grid((n_tris + 255) / 256, n_instances);
   hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, s, p, vout, indices, setup, setup_cap, tile_count, counters, n_tris);
   hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, counters, n_tiles);
@@ -319,7 +372,7 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* 
                      bin_cap, counters);
 }
 
-void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, const uint32_t* tile_count, const uint32_t* tile_offset,
-                   const uint32_t* bin_list, uint32_t* vis, float* depth, int tiles_x, int tiles_y) {
-  hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, tile_offset, bin_list, vis, depth);
+void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* tile_offset,
+                   const uint32_t* bin_list, uint32_t* vis, float* depth, uint32_t* counters, int tiles_x, int tiles_y) {
+  hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, tile_offset, bin_list, vis, depth, counters);
 }

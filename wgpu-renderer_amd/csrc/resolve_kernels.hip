@@ -4,10 +4,13 @@
 // IBL, gamma); background pixels run fs_main of src/shaders/skybox.wgsl:24-33.
 //
 // A hardware rasteriser shades 2x2 quads so that dpdx/dpdy and implicit texture LODs exist.  Here
-// every pixel re-derives its quad: the varyings of the pixel's own triangle are evaluated at the
-// quad's (0,0), (1,0) and (0,1) pixels and differenced (coarse derivatives, shared by the quad).
-// The prefilter cube lookup and the BRDF-table lookup take coordinates that depend on the normal
-// map, so those coordinates are evaluated at the three quad pixels as well.
+// every covered pixel re-derives its quad on its own triangle: the varyings are evaluated at the
+// quad's (0,0), (1,0) and (0,1) pixel centres and differenced (coarse derivatives, shared by the
+// quad).  The prefilter cube lookup and the BRDF-table lookup take coordinates that depend on the
+// normal map, so the normal-mapped reflection vector is evaluated at those three pixels as well.
+// Four consecutive lanes hold one 2x2 quad; when all four pixels of a quad show the same triangle
+// the three helper evaluations are the neighbours' own results and are fetched with cross-lane
+// reads instead of being recomputed.  Background pixels are shaded by a separate, light kernel.
 //
 // Sampling rules: lambda = log2(max(rho_x, rho_y)) with Euclidean rho; the material sampler has
 // mipmapFilter "nearest" (level ceil(lambda+0.5)-1) and picks magFilter when lambda <= 0; cube
@@ -25,7 +28,7 @@ PBR_DEV Lod2D lod_2d(int w, int h, int levels, uint32_t sampler, float2 ddx, flo
   const float fw = (float)w, fh = (float)h;
   const float mux = ddx.x * fw, mvx = ddx.y * fh, muy = ddy.x * fw, mvy = ddy.y * fh;
   const float rho2 = fmaxf(mux * mux + mvx * mvx, muy * muy + mvy * mvy);
-  float lambda = 0.5f * log2f(rho2);     // = log2(rho); -inf when the footprint is zero
+  float lambda = 0.5f * log2_fast(rho2);   // = log2(rho); -inf when the footprint is zero
   if (isnan(lambda)) lambda = 0.0f;
   lambda = fminf(fmaxf(lambda, 0.0f), 32.0f);
   Lod2D r;
@@ -46,8 +49,9 @@ PBR_DEV int wrap_coord(int i, int n, bool repeat) {
 
 PBR_DEV float4 decode8(uint32_t t, bool srgb, const float* s_srgb) {
   const uint32_t r = t & 255u, g = (t >> 8) & 255u, b = (t >> 16) & 255u, a = t >> 24;
-  if (srgb) return make_float4(s_srgb[r], s_srgb[g], s_srgb[b], (float)a / 255.0f);
-  return make_float4((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f, (float)a / 255.0f);
+  const float k = 1.0f / 255.0f;
+  if (srgb) return make_float4(s_srgb[r], s_srgb[g], s_srgb[b], (float)a * k);
+  return make_float4((float)r * k, (float)g * k, (float)b * k, (float)a * k);
 }
 
 PBR_DEV float4 bilerp4(float4 t00, float4 t10, float4 t01, float4 t11, float a, float b) {
@@ -142,8 +146,8 @@ PBR_DEV bool cube_tap(const float4* level, int n, int face, int i, int j, float4
   if (ox || oy) {
     const float sc = ((float)i + 0.5f) / (float)n * 2.0f - 1.0f, tc = ((float)j + 0.5f) / (float)n * 2.0f - 1.0f;
     const CubeCoord c = cube_select(cube_dir(face, sc, tc));
-    const float ma = fabsf(c.rc);
-    const float s = 0.5f * (c.sc / ma) + 0.5f, t = 0.5f * (c.tc / ma) + 0.5f;
+    const float ima = rcp_fast(fabsf(c.rc));
+    const float s = 0.5f * (c.sc * ima) + 0.5f, t = 0.5f * (c.tc * ima) + 0.5f;
     face = c.face;
     i = min(max((int)floorf(s * (float)n), 0), n - 1);
     j = min(max((int)floorf(t * (float)n), 0), n - 1);
@@ -155,8 +159,8 @@ PBR_DEV bool cube_tap(const float4* level, int n, int face, int i, int j, float4
 PBR_DEV float4 cube_sample_level(const DevCube& cube, int level, const CubeCoord& c) {
   const int n = max(1, cube.size >> level);
   const float4* base = cube.base + cube.off[level];
-  const float ma = fabsf(c.rc);
-  const float s = 0.5f * (c.sc / ma) + 0.5f, t = 0.5f * (c.tc / ma) + 0.5f;
+  const float ima = rcp_fast(fabsf(c.rc));
+  const float s = 0.5f * (c.sc * ima) + 0.5f, t = 0.5f * (c.tc * ima) + 0.5f;
   const float tu = s * (float)n - 0.5f, tv = t * (float)n - 0.5f;
   const float fu = floorf(tu), fv = floorf(tv);
   const float a = tu - fu, b = tv - fv;
@@ -177,14 +181,14 @@ PBR_DEV float4 cube_sample_level(const DevCube& cube, int level, const CubeCoord
       float4 s3 = make_float4(0, 0, 0, 0);
 #pragma unroll
       for (int m = 0; m < 4; ++m) if (m != k) { s3.x += tap[m].x; s3.y += tap[m].y; s3.z += tap[m].z; s3.w += tap[m].w; }
-      tap[k] = make_float4(s3.x / 3.0f, s3.y / 3.0f, s3.z / 3.0f, s3.w / 3.0f);
+      tap[k] = make_float4(s3.x * (1.0f / 3.0f), s3.y * (1.0f / 3.0f), s3.z * (1.0f / 3.0f), s3.w * (1.0f / 3.0f));
     }
   return bilerp4(tap[0], tap[1], tap[2], tap[3], a, b);
 }
 
 PBR_DEV float cube_lambda(int size, V3 r, V3 drdx, V3 drdy) {
   const CubeCoord c = cube_select(r);
-  const float ma = fabsf(c.rc), sgn = c.rc >= 0 ? 1.0f : -1.0f, inv_rc2 = 1.0f / (c.rc * c.rc);
+  const float ma = fabsf(c.rc), sgn = c.rc >= 0 ? 1.0f : -1.0f, inv_rc2 = rcp_fast(c.rc * c.rc);
   float rho2[2];
   const V3 d[2] = {drdx, drdy};
 #pragma unroll
@@ -196,7 +200,7 @@ PBR_DEV float cube_lambda(int size, V3 r, V3 drdx, V3 drdy) {
     const float mu = ds * (float)size, mv = dt * (float)size;
     rho2[k] = mu * mu + mv * mv;
   }
-  return 0.5f * log2f(fmaxf(rho2[0], rho2[1]));
+  return 0.5f * log2_fast(fmaxf(rho2[0], rho2[1]));
 }
 
 PBR_DEV float4 cube_sample(const DevCube& cube, V3 r, float lambda) {
@@ -229,51 +233,133 @@ PBR_DEV Varyings blend(const Tri& t, float b0, float b1, float b2) {
   return v;
 }
 
-// Screen-space barycentrics from the snapped vertices (exact integer edge functions), weighted by 1/w.
-struct ProjSetup { long long e0, e1; int a0, b0, a1, b1; float inv_area, iw0, iw1, iw2; };
-
-PBR_DEV Varyings interp_proj(const Tri& t, const ProjSetup& s, int dx, int dy) {
-  const long long e0 = s.e0 + (long long)s.a0 * (dx * 256) + (long long)s.b0 * (dy * 256);
-  const long long e1 = s.e1 + (long long)s.a1 * (dx * 256) + (long long)s.b1 * (dy * 256);
-  const float l0 = (float)e0 * s.inv_area, l1 = (float)e1 * s.inv_area, l2 = (1.0f - l0) - l1;
-  const float q0 = l0 * s.iw0, q1 = l1 * s.iw1, q2 = l2 * s.iw2;
-  const float inv = 1.0f / ((q0 + q1) + q2);
-  return blend(t, q0 * inv, q1 * inv, q2 * inv);
-}
-
-// A vertex behind the eye or beyond the guard band: 2D homogeneous barycentrics at the pixel centre.
-PBR_DEV Varyings interp_homog(const Tri& t, int x, int y, int W, int H) {
-  const float xn = ((float)x + 0.5f) / (float)W * 2.0f - 1.0f, yn = 1.0f - ((float)y + 0.5f) / (float)H * 2.0f;
-  const float4 c0 = t.c0, c1 = t.c1, c2 = t.c2;
-  const float h0 = (c1.y * c2.w - c2.y * c1.w) * xn + (c2.x * c1.w - c1.x * c2.w) * yn + (c1.x * c2.y - c2.x * c1.y);
-  const float h1 = (c2.y * c0.w - c0.y * c2.w) * xn + (c0.x * c2.w - c2.x * c0.w) * yn + (c2.x * c0.y - c0.x * c2.y);
-  const float h2 = (c0.y * c1.w - c1.y * c0.w) * xn + (c1.x * c0.w - c0.x * c1.w) * yn + (c0.x * c1.y - c1.x * c0.y);
-  const float inv = 1.0f / ((h0 + h1) + h2);
-  return blend(t, h0 * inv, h1 * inv, h2 * inv);
-}
-
 PBR_DEV void snap_xy(float4 c, int W, int H, int& X, int& Y) {
   const float nx = div_rn(c.x, c.w), ny = div_rn(c.y, c.w);
   X = __float2int_rn(mul_rn(mul_rn(mul_rn(add_rn(nx, 1.0f), 0.5f), (float)W), 256.0f));
   Y = __float2int_rn(mul_rn(mul_rn(mul_rn(sub_rn(1.0f, ny), 0.5f), (float)H), 256.0f));
 }
 
-// ---------------- shading ----------------
-struct QuadShared { float2 duvdx, duvdy; V3 T; Lod2D lod_normal, lod_mr; };
-struct FragCommon { V3 normal, view_dir, R; float ndotv, roughness, metalness; };
+// Screen-space barycentrics of one triangle over one quad.  They come from the snapped vertices
+// through integer edge functions at the quad's first pixel centre; the other three centres are one
+// pixel step away, added in f32.
+struct QuadBary {
+  bool projective;
+  float l0, l1;                 // barycentrics of vertices 0 and 1 at pixel (0,0) of the quad
+  float l0x, l0y, l1x, l1y;     // their change per pixel in x and y
+  float iw0, iw1, iw2;          // 1 / w of the three vertices
+};
 
-// shader.wgsl:96, :101-107, :111, :148 for one invocation (own pixel or a quad neighbour).
-PBR_DEV FragCommon eval_common(const FrameParams* p, const ResolveInputs& in, const QuadShared& q, const Varyings& v, const float* s_srgb) {
+PBR_DEV QuadBary quad_bary(const Tri& t, int qx, int qy, int W, int H) {
+  QuadBary b;
+  b.projective = t.c0.w > 0.0f && t.c1.w > 0.0f && t.c2.w > 0.0f && fabsf(t.c0.x) <= PBR_GUARD * t.c0.w && fabsf(t.c0.y) <= PBR_GUARD * t.c0.w &&
+                 fabsf(t.c1.x) <= PBR_GUARD * t.c1.w && fabsf(t.c1.y) <= PBR_GUARD * t.c1.w && fabsf(t.c2.x) <= PBR_GUARD * t.c2.w &&
+                 fabsf(t.c2.y) <= PBR_GUARD * t.c2.w;
+  if (b.projective) {
+    int X0, Y0, X1, Y1, X2, Y2;
+    snap_xy(t.c0, W, H, X0, Y0); snap_xy(t.c1, W, H, X1, Y1); snap_xy(t.c2, W, H, X2, Y2);
+    const long long area = (long long)(X1 - X0) * (Y2 - Y0) - (long long)(X2 - X0) * (Y1 - Y0);
+    if (area == 0) { b.projective = false; return b; }
+    const long long px = (long long)qx * 256 + 128, py = (long long)qy * 256 + 128;
+    const int a0 = -(Y2 - Y1), b0 = X2 - X1, a1 = -(Y0 - Y2), b1 = X0 - X2;
+    const long long e0 = (long long)b0 * (py - Y1) + (long long)a0 * (px - X1);
+    const long long e1 = (long long)b1 * (py - Y2) + (long long)a1 * (px - X2);
+    const float inv_area = rcp_fast((float)area);
+    b.l0 = (float)e0 * inv_area; b.l1 = (float)e1 * inv_area;
+    b.l0x = (float)(a0 * 256) * inv_area; b.l0y = (float)(b0 * 256) * inv_area;
+    b.l1x = (float)(a1 * 256) * inv_area; b.l1y = (float)(b1 * 256) * inv_area;
+    b.iw0 = rcp_fast(t.c0.w); b.iw1 = rcp_fast(t.c1.w); b.iw2 = rcp_fast(t.c2.w);
+  }
+  return b;
+}
+
+// Perspective-correct varyings at pixel (qx + dx, qy + dy), dx, dy in {0, 1}.
+PBR_DEV Varyings varyings_at(const Tri& t, const QuadBary& b, int qx, int qy, int dx, int dy, int W, int H) {
+  if (b.projective) {
+    const float l0 = b.l0 + (dx ? b.l0x : 0.0f) + (dy ? b.l0y : 0.0f);
+    const float l1 = b.l1 + (dx ? b.l1x : 0.0f) + (dy ? b.l1y : 0.0f);
+    const float l2 = (1.0f - l0) - l1;
+    const float q0 = l0 * b.iw0, q1 = l1 * b.iw1, q2 = l2 * b.iw2;
+    const float inv = rcp_fast((q0 + q1) + q2);
+    return blend(t, q0 * inv, q1 * inv, q2 * inv);
+  }
+  // a vertex behind the eye or beyond the guard band: 2D homogeneous barycentrics at the pixel centre
+  const float xn = ((float)(qx + dx) + 0.5f) / (float)W * 2.0f - 1.0f, yn = 1.0f - ((float)(qy + dy) + 0.5f) / (float)H * 2.0f;
+  const float4 c0 = t.c0, c1 = t.c1, c2 = t.c2;
+  const float h0 = (c1.y * c2.w - c2.y * c1.w) * xn + (c2.x * c1.w - c1.x * c2.w) * yn + (c1.x * c2.y - c2.x * c1.y);
+  const float h1 = (c2.y * c0.w - c0.y * c2.w) * xn + (c0.x * c2.w - c2.x * c0.w) * yn + (c2.x * c0.y - c0.x * c2.y);
+  const float h2 = (c0.y * c1.w - c1.y * c0.w) * xn + (c1.x * c0.w - c0.x * c1.w) * yn + (c0.x * c1.y - c1.x * c0.y);
+  const float inv = rcp_fast((h0 + h1) + h2);
+  return blend(t, h0 * inv, h1 * inv, h2 * inv);
+}
+
+// ---------------- shading ----------------
+// FAST = the reference's default sampler (repeat / repeat / linear / linear, renderer.ts:1762-1768) on
+// five power-of-two textures of one size: no address-mode or filter branches, one bilinear
+// footprint per invocation shared by every texture, and no derivatives for the BRDF table because
+// magFilter == minFilter.
+struct Footprint { uint32_t o00, o10, o01, o11; float w00, w10, w01, w11; bool nan; };
+
+PBR_DEV Footprint footprint_fast(const DevTex8& t, int level, float u, float v) {
+  Footprint f;
+  f.nan = isnan(u) || isnan(v);
+  const int lw = t.w >> level, lh = t.h >> level;   // powers of two, at least 1
+  const float tu = u * (float)lw - 0.5f, tv = v * (float)lh - 0.5f;
+  const float fu = floorf(tu), fv = floorf(tv), a = tu - fu, b = tv - fv;
+  const int x0 = (int)fu & (lw - 1), x1 = ((int)fu + 1) & (lw - 1), y0 = (int)fv & (lh - 1), y1 = ((int)fv + 1) & (lh - 1);
+  const uint32_t base = t.off[level], r0 = base + (uint32_t)y0 * lw, r1 = base + (uint32_t)y1 * lw;
+  f.o00 = r0 + x0; f.o10 = r0 + x1; f.o01 = r1 + x0; f.o11 = r1 + x1;
+  f.w00 = (1.0f - a) * (1.0f - b); f.w10 = a * (1.0f - b); f.w01 = (1.0f - a) * b; f.w11 = a * b;
+  return f;
+}
+
+PBR_DEV V3 fetch_fast(const DevTex8& t, const Footprint& f, const float* s_srgb) {
+  const uint32_t a = t.base[f.o00], b = t.base[f.o10], c = t.base[f.o01], d = t.base[f.o11];
+  V3 r;
+  if (t.srgb) {
+    r.x = ((s_srgb[a & 255u] * f.w00 + s_srgb[b & 255u] * f.w10) + s_srgb[c & 255u] * f.w01) + s_srgb[d & 255u] * f.w11;
+    r.y = ((s_srgb[(a >> 8) & 255u] * f.w00 + s_srgb[(b >> 8) & 255u] * f.w10) + s_srgb[(c >> 8) & 255u] * f.w01) + s_srgb[(d >> 8) & 255u] * f.w11;
+    r.z = ((s_srgb[(a >> 16) & 255u] * f.w00 + s_srgb[(b >> 16) & 255u] * f.w10) + s_srgb[(c >> 16) & 255u] * f.w01) + s_srgb[(d >> 16) & 255u] * f.w11;
+  } else {
+    const float k = 1.0f / 255.0f;
+    r.x = (((float)(a & 255u) * f.w00 + (float)(b & 255u) * f.w10) + (float)(c & 255u) * f.w01 + (float)(d & 255u) * f.w11) * k;
+    r.y = (((float)((a >> 8) & 255u) * f.w00 + (float)((b >> 8) & 255u) * f.w10) + (float)((c >> 8) & 255u) * f.w01 + (float)((d >> 8) & 255u) * f.w11) * k;
+    r.z = (((float)((a >> 16) & 255u) * f.w00 + (float)((b >> 16) & 255u) * f.w10) + (float)((c >> 16) & 255u) * f.w01 + (float)((d >> 16) & 255u) * f.w11) * k;
+  }
+  if (f.nan) { const float n = __int_as_float(0x7fc00000); r = v3(n, n, n); }
+  return r;
+}
+
+struct QuadShared { float2 duvdx, duvdy; V3 T; Lod2D lod[5]; };
+// What one invocation (owned pixel or helper) contributes to the derivative-dependent lookups.
+struct Eval { V3 normal, view_dir, R; float ndotv, roughness, metalness; };
+
+// shader.wgsl:96, :101-107, :111, :148 for one invocation.  `with_mr` also samples the
+// metallic-roughness map (helpers need it only for the BRDF-table derivatives of the general samplers).
+template <bool FAST>
+PBR_DEV Eval eval_invocation(const FrameParams* p, const ResolveInputs& in, const QuadShared& q, const Varyings& v, const float* s_srgb, bool with_mr,
+                             Footprint* fp_out) {
   const uint32_t sampler = p->u.sampler_index;
-  FragCommon o;
-  const float4 ns = sample_2d(in.tex[PBR_TEX_NORMAL], q.lod_normal, sampler, v.uv.x, v.uv.y, s_srgb);
-  const V3 tn = v3(ns.x * 2.0f - 1.0f, ns.y * 2.0f - 1.0f, ns.z * 2.0f - 1.0f);
-  const V3 N = normalize(v.normal);
-  const V3 B = -normalize(cross(N, q.T));
-  o.normal = normalize(q.T * tn.x + B * tn.y + N * tn.z);
-  const float4 mr = sample_2d(in.tex[PBR_TEX_METALLIC_ROUGHNESS], q.lod_mr, sampler, v.uv.x, v.uv.y, s_srgb);
-  o.metalness = mr.z; o.roughness = mr.y;
-  o.view_dir = normalize(v3(p->u.view_pos[0], p->u.view_pos[1], p->u.view_pos[2]) - v.pos);
+  Eval o;
+  V3 tn;
+  o.roughness = 0.0f; o.metalness = 0.0f;
+  if constexpr (FAST) {
+    const Footprint fp = footprint_fast(in.tex[PBR_TEX_NORMAL], q.lod[PBR_TEX_NORMAL].level, v.uv.x, v.uv.y);
+    const V3 ns = fetch_fast(in.tex[PBR_TEX_NORMAL], fp, s_srgb);
+    tn = v3(ns.x * 2.0f - 1.0f, ns.y * 2.0f - 1.0f, ns.z * 2.0f - 1.0f);
+    if (with_mr) { const V3 mr = fetch_fast(in.tex[PBR_TEX_METALLIC_ROUGHNESS], fp, s_srgb); o.metalness = mr.z; o.roughness = mr.y; }
+    if (fp_out) *fp_out = fp;
+  } else {
+    const float4 ns = sample_2d(in.tex[PBR_TEX_NORMAL], q.lod[PBR_TEX_NORMAL], sampler, v.uv.x, v.uv.y, s_srgb);
+    tn = v3(ns.x * 2.0f - 1.0f, ns.y * 2.0f - 1.0f, ns.z * 2.0f - 1.0f);
+    if (with_mr) {
+      const float4 mr = sample_2d(in.tex[PBR_TEX_METALLIC_ROUGHNESS], q.lod[PBR_TEX_METALLIC_ROUGHNESS], sampler, v.uv.x, v.uv.y, s_srgb);
+      o.metalness = mr.z; o.roughness = mr.y;
+    }
+  }
+  const V3 N = normalize_fast(v.normal);
+  const V3 B = -normalize_fast(cross(N, q.T));
+  o.normal = normalize_fast(q.T * tn.x + B * tn.y + N * tn.z);
+  o.view_dir = normalize_fast(v3(p->u.view_pos[0], p->u.view_pos[1], p->u.view_pos[2]) - v.pos);
   const V3 I = -o.view_dir;
   const V3 R = I - o.normal * (2.0f * dot(o.normal, I));   // reflect(-viewDir, normal)
   o.R = v3(R.x, R.y, -R.z);
@@ -281,155 +367,475 @@ PBR_DEV FragCommon eval_common(const FrameParams* p, const ResolveInputs& in, co
   return o;
 }
 
-PBR_DEV float smith_ggx(float c, float k) { return c / (c * (1.0f - k) + k); }   // shader.wgsl:83-91
+PBR_DEV float smith_ggx(float c, float k) { return c * rcp_fast(c * (1.0f - k) + k); }   // shader.wgsl:83-91
 
 PBR_DEV uint32_t pack_color(V3 color) {
-  const float g = 1.0f / 2.2f;   // shader.wgsl:157, skybox.wgsl:30
-  return to_unorm8(powf(color.x, g)) | (to_unorm8(powf(color.y, g)) << 8) | (to_unorm8(powf(color.z, g)) << 16) | 0xff000000u;
+  // pow(c, 1/2.2) as exp2(log2(c) / 2.2) (shader.wgsl:157, skybox.wgsl:30): 0 -> 0, negative or NaN -> NaN -> 0
+  const float g = 1.0f / 2.2f;
+  return to_unorm8(exp2_fast(log2_fast(color.x) * g)) | (to_unorm8(exp2_fast(log2_fast(color.y) * g)) << 8) |
+         (to_unorm8(exp2_fast(log2_fast(color.z) * g)) << 16) | 0xff000000u;
 }
 
-PBR_DEV uint32_t shade_sky(const FrameParams* p, const DevCube& sky, int x, int y) {
-  const float* m = p->u.inv_view_proj;
-  const float xn = ((float)x + 0.5f) / (float)p->W * 2.0f - 1.0f, yn = 1.0f - ((float)y + 0.5f) / (float)p->H * 2.0f;
-  const float tx = ((m[0] * xn + m[4] * yn) + m[8]) + m[12];
-  const float ty = ((m[1] * xn + m[5] * yn) + m[9]) + m[13];
-  const float tz = ((m[2] * xn + m[6] * yn) + m[10]) + m[14];
-  const float tw = ((m[3] * xn + m[7] * yn) + m[11]) + m[15];
-  const V3 d = normalize(v3(tx / tw, ty / tw, tz / tw));
-  const float4 c = cube_sample(sky, v3(d.x, d.y, -d.z), 0.0f);
-  return pack_color(v3(c.x, c.y, c.z));
-}
-
-PBR_DEV uint32_t shade_surface(const FrameParams* p, const ResolveInputs& in, uint32_t id, int x, int y, const float* s_srgb) {
+// fs_main after the derivative-dependent part (shader.wgsl:95, :108-159) for one owned pixel.
+template <bool FAST>
+PBR_DEV uint32_t shade_owned(const FrameParams* p, const ResolveInputs& in, const QuadShared& q, const Varyings& f, const Eval& fc, const Footprint& fp,
+                             float lambda, float2 lut_dx, float2 lut_dy, const float* s_srgb) {
   const uint32_t sampler = p->u.sampler_index;
-  // ---- fetch the triangle ----
-  uint32_t inst = 0, tri = id;
-  if (p->n_instances > 1) { inst = id / (uint32_t)p->n_tris; tri = id - inst * (uint32_t)p->n_tris; }
-  const VertexOut* vb = in.vout + (size_t)inst * p->n_verts;
-  const VertexOut v0 = vb[in.indices[3 * tri]], v1 = vb[in.indices[3 * tri + 1]], v2 = vb[in.indices[3 * tri + 2]];
-  Tri t;
-  t.c0 = v0.clip; t.c1 = v1.clip; t.c2 = v2.clip;
-  t.p0 = v3(v0.world_u.x, v0.world_u.y, v0.world_u.z); t.p1 = v3(v1.world_u.x, v1.world_u.y, v1.world_u.z); t.p2 = v3(v2.world_u.x, v2.world_u.y, v2.world_u.z);
-  t.n0 = v3(v0.nrm_v.x, v0.nrm_v.y, v0.nrm_v.z); t.n1 = v3(v1.nrm_v.x, v1.nrm_v.y, v1.nrm_v.z); t.n2 = v3(v2.nrm_v.x, v2.nrm_v.y, v2.nrm_v.z);
-  t.t0 = make_float2(v0.world_u.w, v0.nrm_v.w); t.t1 = make_float2(v1.world_u.w, v1.nrm_v.w); t.t2 = make_float2(v2.world_u.w, v2.nrm_v.w);
-
-  // ---- varyings at the quad's three reference pixels and at this pixel ----
-  const int qx = x & ~1, qy = y & ~1;
-  bool projective = t.c0.w > 0.0f && t.c1.w > 0.0f && t.c2.w > 0.0f && fabsf(t.c0.x) <= PBR_GUARD * t.c0.w && fabsf(t.c0.y) <= PBR_GUARD * t.c0.w &&
-                    fabsf(t.c1.x) <= PBR_GUARD * t.c1.w && fabsf(t.c1.y) <= PBR_GUARD * t.c1.w && fabsf(t.c2.x) <= PBR_GUARD * t.c2.w &&
-                    fabsf(t.c2.y) <= PBR_GUARD * t.c2.w;
-  ProjSetup ps = {};
-  if (projective) {
-    int X0, Y0, X1, Y1, X2, Y2;
-    snap_xy(t.c0, p->W, p->H, X0, Y0); snap_xy(t.c1, p->W, p->H, X1, Y1); snap_xy(t.c2, p->W, p->H, X2, Y2);
-    const long long area = (long long)(X1 - X0) * (Y2 - Y0) - (long long)(X2 - X0) * (Y1 - Y0);
-    if (area == 0) projective = false;
-    else {
-      const long long px = (long long)qx * 256 + 128, py = (long long)qy * 256 + 128;
-      ps.a0 = -(Y2 - Y1); ps.b0 = X2 - X1; ps.a1 = -(Y0 - Y2); ps.b1 = X0 - X2;
-      ps.e0 = (long long)ps.b0 * (py - Y1) + (long long)ps.a0 * (px - X1);
-      ps.e1 = (long long)ps.b1 * (py - Y2) + (long long)ps.a1 * (px - X2);
-      ps.inv_area = 1.0f / (float)area;
-      ps.iw0 = 1.0f / t.c0.w; ps.iw1 = 1.0f / t.c1.w; ps.iw2 = 1.0f / t.c2.w;
-    }
-  }
-  Varyings h0, h1, h2, f;
-  if (projective) {
-    h0 = interp_proj(t, ps, 0, 0); h1 = interp_proj(t, ps, 1, 0); h2 = interp_proj(t, ps, 0, 1); f = interp_proj(t, ps, x - qx, y - qy);
-  } else {
-    h0 = interp_homog(t, qx, qy, p->W, p->H); h1 = interp_homog(t, qx + 1, qy, p->W, p->H); h2 = interp_homog(t, qx, qy + 1, p->W, p->H);
-    f = interp_homog(t, x, y, p->W, p->H);
-  }
-
-  // ---- quad-shared derivatives (shader.wgsl:97-102) ----
-  QuadShared q;
-  const V3 q1 = h1.pos - h0.pos, q2 = h2.pos - h0.pos;
-  q.duvdx = make_float2(h1.uv.x - h0.uv.x, h1.uv.y - h0.uv.y);
-  q.duvdy = make_float2(h2.uv.x - h0.uv.x, h2.uv.y - h0.uv.y);
-  q.T = normalize(q1 * q.duvdy.y - q2 * q.duvdx.y);
-  const int use_mips = p->u.use_mipmaps;
-  Lod2D lod[5];
-#pragma unroll
-  for (int i = 0; i < 5; ++i) lod[i] = lod_2d(in.tex[i].w, in.tex[i].h, use_mips ? in.tex[i].levels : 1, sampler, q.duvdx, q.duvdy);
-  q.lod_normal = lod[PBR_TEX_NORMAL]; q.lod_mr = lod[PBR_TEX_METALLIC_ROUGHNESS];
-
-  const FragCommon c0 = eval_common(p, in, q, h0, s_srgb), c1 = eval_common(p, in, q, h1, s_srgb), c2 = eval_common(p, in, q, h2, s_srgb);
-  const FragCommon fc = eval_common(p, in, q, f, s_srgb);
   const V3 normal = fc.normal, view_dir = fc.view_dir;
   const float metalness = fc.metalness, roughness = fc.roughness, ndotv = fc.ndotv;
-
-  // ---- material (shader.wgsl:95, :108-109) ----
-  const float4 alb4 = sample_2d(in.tex[PBR_TEX_ALBEDO], lod[PBR_TEX_ALBEDO], sampler, f.uv.x, f.uv.y, s_srgb);
-  const V3 albedo = v3(alb4.x, alb4.y, alb4.z);
-  const float4 em4 = sample_2d(in.tex[PBR_TEX_EMISSIVE], lod[PBR_TEX_EMISSIVE], sampler, f.uv.x, f.uv.y, s_srgb);
-  const V3 emissive = v3(em4.x * p->u.emissive_factor[0], em4.y * p->u.emissive_factor[1], em4.z * p->u.emissive_factor[2]);
-  const float occlusion = sample_2d(in.tex[PBR_TEX_OCCLUSION], lod[PBR_TEX_OCCLUSION], sampler, f.uv.x, f.uv.y, s_srgb).x;
+  V3 albedo, emissive;
+  float occlusion;
+  if constexpr (FAST) {
+    albedo = fetch_fast(in.tex[PBR_TEX_ALBEDO], fp, s_srgb);
+    emissive = fetch_fast(in.tex[PBR_TEX_EMISSIVE], fp, s_srgb);
+    occlusion = fetch_fast(in.tex[PBR_TEX_OCCLUSION], fp, s_srgb).x;
+  } else {
+    const float4 alb4 = sample_2d(in.tex[PBR_TEX_ALBEDO], q.lod[PBR_TEX_ALBEDO], sampler, f.uv.x, f.uv.y, s_srgb);
+    albedo = v3(alb4.x, alb4.y, alb4.z);
+    const float4 em4 = sample_2d(in.tex[PBR_TEX_EMISSIVE], q.lod[PBR_TEX_EMISSIVE], sampler, f.uv.x, f.uv.y, s_srgb);
+    emissive = v3(em4.x, em4.y, em4.z);
+    occlusion = sample_2d(in.tex[PBR_TEX_OCCLUSION], q.lod[PBR_TEX_OCCLUSION], sampler, f.uv.x, f.uv.y, s_srgb).x;
+  }
+  emissive = v3(emissive.x * p->u.emissive_factor[0], emissive.y * p->u.emissive_factor[1], emissive.z * p->u.emissive_factor[2]);
   const float om = 1.0f - metalness;
   const V3 f0 = v3(0.04f * om + albedo.x * metalness, 0.04f * om + albedo.y * metalness, 0.04f * om + albedo.z * metalness);
 
-  // ---- four point lights (shader.wgsl:118-139) ----
+  // four point lights (shader.wgsl:118-139)
   V3 Lo = v3(0, 0, 0);
   const float a = roughness * roughness, a2 = a * a;
-  const float rk = roughness + 1.0f, k = (rk * rk) / 8.0f;
+  const float rk = roughness + 1.0f, k = (rk * rk) * 0.125f;
   const float g_v = smith_ggx(ndotv, k);
+  const float inv_pi = 1.0f / PI_F;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const V3 to_light = v3(p->u.light_pos[i][0], p->u.light_pos[i][1], p->u.light_pos[i][2]) - f.pos;
-    const float dist2 = dot(to_light, to_light), dist = sqrtf(dist2);
-    const V3 light_dir = v3(to_light.x / dist, to_light.y / dist, to_light.z / dist);
-    const V3 halfway = normalize(view_dir + light_dir);
-    const float attenuation = 1.0f / (dist * dist);
+    const float dist2 = dot(to_light, to_light), inv_dist = rsq_fast(dist2);
+    const V3 light_dir = to_light * inv_dist;
+    const V3 halfway = normalize_fast(view_dir + light_dir);
+    const float attenuation = inv_dist * inv_dist;
     const float ndoth = fmaxf(dot(normal, halfway), 0.0f);
     float denom = ndoth * ndoth * (a2 - 1.0f) + 1.0f;
     denom = PI_F * denom * denom;
-    const float D = a2 / denom;
+    const float D = a2 * rcp_fast(denom);
     const float fcw = pow5(clamp01(1.0f - fmaxf(dot(halfway, view_dir), 0.0f)));
     const V3 F = v3(f0.x + (1.0f - f0.x) * fcw, f0.y + (1.0f - f0.y) * fcw, f0.z + (1.0f - f0.z) * fcw);
     const float ndotl = fmaxf(dot(normal, light_dir), 0.0f);
     const float G = g_v * smith_ggx(ndotl, k);
-    const float sden = 4.0f * ndotv * ndotl + 0.001f;
+    const float dg = D * G * rcp_fast(4.0f * ndotv * ndotl + 0.001f);
     const V3 kD = v3((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
-    const V3 radiance = v3(p->u.light_color[i][0] * attenuation, p->u.light_color[i][1] * attenuation, p->u.light_color[i][2] * attenuation);
-    Lo.x += (kD.x * albedo.x / PI_F + D * F.x * G / sden) * radiance.x * ndotl;
-    Lo.y += (kD.y * albedo.y / PI_F + D * F.y * G / sden) * radiance.y * ndotl;
-    Lo.z += (kD.z * albedo.z / PI_F + D * F.z * G / sden) * radiance.z * ndotl;
+    const float sc = attenuation * ndotl;
+    Lo.x += (kD.x * albedo.x * inv_pi + dg * F.x) * (p->u.light_color[i][0] * sc);
+    Lo.y += (kD.y * albedo.y * inv_pi + dg * F.y) * (p->u.light_color[i][1] * sc);
+    Lo.z += (kD.z * albedo.z * inv_pi + dg * F.z) * (p->u.light_color[i][2] * sc);
   }
 
-  // ---- image-based lighting (shader.wgsl:141-153) ----
+  // image-based lighting (shader.wgsl:141-153)
   const float fcw = pow5(clamp01(1.0f - ndotv));
   const float omr = 1.0f - roughness;
   const V3 kS = v3(f0.x + (fmaxf(omr, f0.x) - f0.x) * fcw, f0.y + (fmaxf(omr, f0.y) - f0.y) * fcw, f0.z + (fmaxf(omr, f0.z) - f0.z) * fcw);
   const V3 kD = v3((1.0f - kS.x) * om, (1.0f - kS.y) * om, (1.0f - kS.z) * om);
   const float4 irr = cube_sample(in.irr, v3(normal.x, normal.y, -normal.z), 0.0f);
   const V3 diffuse = v3(irr.x * albedo.x, irr.y * albedo.y, irr.z * albedo.z);
-  const float lambda = cube_lambda(in.pre.size, fc.R, c1.R - c0.R, c2.R - c0.R);
   const float4 pf = cube_sample(in.pre, fc.R, lambda);
-  const float2 brdf = sample_lut(in.lut, in.lut_size, sampler, ndotv, roughness, make_float2(c1.ndotv - c0.ndotv, c1.roughness - c0.roughness),
-                                 make_float2(c2.ndotv - c0.ndotv, c2.roughness - c0.roughness));
+  const float2 brdf = sample_lut(in.lut, in.lut_size, sampler, ndotv, roughness, lut_dx, lut_dy);
   const V3 specular = v3(pf.x * (kS.x * brdf.x + brdf.y), pf.y * (kS.y * brdf.x + brdf.y), pf.z * (kS.z * brdf.x + brdf.y));
   const V3 ambient = v3((kD.x * diffuse.x + specular.x) * occlusion, (kD.y * diffuse.y + specular.y) * occlusion, (kD.z * diffuse.z + specular.z) * occlusion);
   return pack_color(v3(ambient.x + Lo.x + emissive.x, ambient.y + Lo.y + emissive.y, ambient.z + Lo.z + emissive.z));
 }
 
-__global__ void __launch_bounds__(256) resolve_kernel(const FrameParams* __restrict__ p, ResolveInputs in, const float* __restrict__ srgb_lut,
-                                                      const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8, uint32_t* __restrict__ covered) {
+PBR_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src)); }
+
+// One thread per covered pixel.  Lanes 4q..4q+3 of a wavefront are the pixels (0,0), (1,0), (0,1),
+// (1,1) of quad q; a wavefront covers 32 x 2 pixels, a workgroup 32 x 8.
+template <bool FAST>
+__global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams* __restrict__ p, ResolveInputs in, const float* __restrict__ srgb_lut,
+                                                              const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8) {
   __shared__ float s_srgb[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 3, quad = lane >> 2;
+  const int qx = blockIdx.x * 32 + quad * 2, qy = p->y0 + blockIdx.y * 8 + wave * 2;
+  const int x = qx + (sub & 1), y = qy + (sub >> 1);
+  const bool live = x < p->W && y < p->y1;
+  const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
+  const uint32_t id = live ? vis[o] : 0u;
+  if (__syncthreads_or(id != 0u) == 0) return;   // nothing but background in this workgroup
   s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
   __syncthreads();
-  const int x = blockIdx.x * 32 + (threadIdx.x & 31), y = p->y0 + blockIdx.y * 8 + (threadIdx.x >> 5);
+  if (__ballot(id != 0u) == 0ull) return;
+  // ids of the quad's pixels (0,0), (1,0), (0,1): helper results can be borrowed from a lane that shows the same triangle
+  const int qbase = lane & ~3;
+  const uint32_t id0 = __shfl(id, qbase), id1 = __shfl(id, qbase + 1), id2 = __shfl(id, qbase + 2);
+  const bool share0 = id0 == id, share1 = id1 == id, share2 = id2 == id;
+  const bool need_explicit = id != 0u && !(share0 && share1 && share2);
+  const bool any_explicit = __any(need_explicit);
+
+  uint32_t color = 0;
+  Varyings f;
+  Eval fc;
+  QuadShared q;
+  Footprint fp;
+  V3 R0, R1, R2;
+  float2 lut0 = make_float2(0, 0), lut1 = make_float2(0, 0), lut2 = make_float2(0, 0);
+  Tri t;
+  QuadBary qb;
+  if (id != 0u) {
+    uint32_t inst = 0, tri = id - 1u;
+    if (p->n_instances > 1) { inst = tri / (uint32_t)p->n_tris; tri -= inst * (uint32_t)p->n_tris; }
+    const VertexOut* vb = in.vout + (size_t)inst * p->n_verts;
+    const VertexOut v0 = vb[in.indices[3 * tri]], v1 = vb[in.indices[3 * tri + 1]], v2 = vb[in.indices[3 * tri + 2]];
+    t.c0 = v0.clip; t.c1 = v1.clip; t.c2 = v2.clip;
+    t.p0 = v3(v0.world_u.x, v0.world_u.y, v0.world_u.z); t.p1 = v3(v1.world_u.x, v1.world_u.y, v1.world_u.z); t.p2 = v3(v2.world_u.x, v2.world_u.y, v2.world_u.z);
+    t.n0 = v3(v0.nrm_v.x, v0.nrm_v.y, v0.nrm_v.z); t.n1 = v3(v1.nrm_v.x, v1.nrm_v.y, v1.nrm_v.z); t.n2 = v3(v2.nrm_v.x, v2.nrm_v.y, v2.nrm_v.z);
+    t.t0 = make_float2(v0.world_u.w, v0.nrm_v.w); t.t1 = make_float2(v1.world_u.w, v1.nrm_v.w); t.t2 = make_float2(v2.world_u.w, v2.nrm_v.w);
+    qb = quad_bary(t, qx, qy, p->W, p->H);
+    const Varyings h0 = varyings_at(t, qb, qx, qy, 0, 0, p->W, p->H), h1 = varyings_at(t, qb, qx, qy, 1, 0, p->W, p->H),
+                   h2 = varyings_at(t, qb, qx, qy, 0, 1, p->W, p->H);
+    f = sub == 0 ? h0 : sub == 1 ? h1 : sub == 2 ? h2 : varyings_at(t, qb, qx, qy, 1, 1, p->W, p->H);
+    // quad-shared derivatives (shader.wgsl:97-102)
+    const V3 q1 = h1.pos - h0.pos, q2 = h2.pos - h0.pos;
+    q.duvdx = make_float2(h1.uv.x - h0.uv.x, h1.uv.y - h0.uv.y);
+    q.duvdy = make_float2(h2.uv.x - h0.uv.x, h2.uv.y - h0.uv.y);
+    q.T = normalize_fast(q1 * q.duvdy.y - q2 * q.duvdx.y);
+    const uint32_t sampler = p->u.sampler_index;
+    const int use_mips = p->u.use_mipmaps;
+    if constexpr (FAST) {
+      const Lod2D l = lod_2d(in.tex[0].w, in.tex[0].h, use_mips ? in.tex[0].levels : 1, sampler, q.duvdx, q.duvdy);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) q.lod[i] = l;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) q.lod[i] = lod_2d(in.tex[i].w, in.tex[i].h, use_mips ? in.tex[i].levels : 1, sampler, q.duvdx, q.duvdy);
+    }
+    fc = eval_invocation<FAST>(p, in, q, f, s_srgb, true, &fp);
+    if (need_explicit) {
+      // this pixel's quad shows more than one triangle: evaluate the missing helpers on this pixel's own triangle
+      const Eval e0 = eval_invocation<FAST>(p, in, q, h0, s_srgb, !FAST, nullptr);
+      const Eval e1 = eval_invocation<FAST>(p, in, q, h1, s_srgb, !FAST, nullptr);
+      const Eval e2 = eval_invocation<FAST>(p, in, q, h2, s_srgb, !FAST, nullptr);
+      R0 = e0.R; R1 = e1.R; R2 = e2.R;
+      lut0 = make_float2(e0.ndotv, e0.roughness); lut1 = make_float2(e1.ndotv, e1.roughness); lut2 = make_float2(e2.ndotv, e2.roughness);
+    }
+  }
+  (void)any_explicit;
+  // borrow the helper results of uniform quads from the neighbouring lanes (all lanes take part in the exchange)
+  {
+    const V3 s0 = shfl3(fc.R, qbase), s1 = shfl3(fc.R, qbase + 1), s2 = shfl3(fc.R, qbase + 2);
+    const float n0 = __shfl(fc.ndotv, qbase), n1 = __shfl(fc.ndotv, qbase + 1), n2 = __shfl(fc.ndotv, qbase + 2);
+    const float r0 = __shfl(fc.roughness, qbase), r1 = __shfl(fc.roughness, qbase + 1), r2 = __shfl(fc.roughness, qbase + 2);
+    if (!need_explicit) { R0 = s0; R1 = s1; R2 = s2; lut0 = make_float2(n0, r0); lut1 = make_float2(n1, r1); lut2 = make_float2(n2, r2); }
+  }
+  if (id != 0u) {
+    const float lambda = cube_lambda(in.pre.size, fc.R, R1 - R0, R2 - R0);   // implicit LOD of shader.wgsl:149
+    color = shade_owned<FAST>(p, in, q, f, fc, fp, lambda, make_float2(lut1.x - lut0.x, lut1.y - lut0.y), make_float2(lut2.x - lut0.x, lut2.y - lut0.y), s_srgb);
+    rgba8[o] = color;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The specialised surface kernel.  Same arithmetic as resolve_surface_kernel<true>, arranged so that
+// a pixel's memory accesses happen in five rounds of independent loads — visibility id, indices,
+// vertices, all material texels (own pixel and helpers), all IBL texels — instead of one round per
+// lookup: the kernel is latency-bound, so the number of dependent rounds sets its speed.
+// ---------------------------------------------------------------------------------------------
+struct CubeFoot { uint32_t o[4]; float w[4]; };
+
+// Texel offsets (from cube.base) and weights of one seamless bilinear lookup on one level.
+PBR_DEV CubeFoot cube_foot(const DevCube& cube, int level, const CubeCoord& c) {
+  CubeFoot f;
+  const int n = max(1, cube.size >> level);
+  const uint32_t base = cube.off[level];
+  const float ima = rcp_fast(fabsf(c.rc));
+  const float s = 0.5f * (c.sc * ima) + 0.5f, t = 0.5f * (c.tc * ima) + 0.5f;
+  const float tu = s * (float)n - 0.5f, tv = t * (float)n - 0.5f;
+  const float fu = floorf(tu), fv = floorf(tv), a = tu - fu, b = tv - fv;
+  const int i0 = (int)fu, j0 = (int)fv;
+  f.w[0] = (1.0f - a) * (1.0f - b); f.w[1] = a * (1.0f - b); f.w[2] = (1.0f - a) * b; f.w[3] = a * b;
+  if (i0 >= 0 && j0 >= 0 && i0 + 1 < n && j0 + 1 < n) {
+    const uint32_t o = base + ((uint32_t)c.face * n + j0) * n + i0;
+    f.o[0] = o; f.o[1] = o + 1; f.o[2] = o + n; f.o[3] = o + n + 1;
+    return f;
+  }
+  int missing = -1;
+  uint32_t valid = base;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    int i = i0 + (k & 1), j = j0 + (k >> 1), face = c.face;
+    const bool ox = i < 0 || i >= n, oy = j < 0 || j >= n;
+    if (ox && oy) { missing = k; f.o[k] = base; continue; }   // beyond a corner: no such texel
+    if (ox || oy) {
+      const float sc = ((float)i + 0.5f) / (float)n * 2.0f - 1.0f, tc = ((float)j + 0.5f) / (float)n * 2.0f - 1.0f;
+      const CubeCoord cc = cube_select(cube_dir(face, sc, tc));
+      const float im = rcp_fast(fabsf(cc.rc));
+      face = cc.face;
+      i = min(max((int)floorf((0.5f * (cc.sc * im) + 0.5f) * (float)n), 0), n - 1);
+      j = min(max((int)floorf((0.5f * (cc.tc * im) + 0.5f) * (float)n), 0), n - 1);
+    }
+    f.o[k] = base + ((uint32_t)face * n + j) * n + i;
+    valid = f.o[k];
+  }
+  if (missing >= 0) {   // the missing corner tap is the mean of the other three: its weight is shared out
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k == missing) continue;
+      f.w[k] += (missing == 0 ? f.w[0] : missing == 1 ? f.w[1] : missing == 2 ? f.w[2] : f.w[3]) * (1.0f / 3.0f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k == missing) { f.w[k] = 0.0f; f.o[k] = valid; }
+  }
+  return f;
+}
+
+PBR_DEV V3 weigh4(const float4 t[4], const float w[4]) {
+  return v3(((t[0].x * w[0] + t[1].x * w[1]) + t[2].x * w[2]) + t[3].x * w[3], ((t[0].y * w[0] + t[1].y * w[1]) + t[2].y * w[2]) + t[3].y * w[3],
+            ((t[0].z * w[0] + t[1].z * w[1]) + t[2].z * w[2]) + t[3].z * w[3]);
+}
+
+template <bool SRGB>
+PBR_DEV V3 decode_fast(const uint32_t t[4], const Footprint& f, const float* s_srgb) {
+  V3 r;
+  if constexpr (SRGB) {
+    r.x = ((s_srgb[t[0] & 255u] * f.w00 + s_srgb[t[1] & 255u] * f.w10) + s_srgb[t[2] & 255u] * f.w01) + s_srgb[t[3] & 255u] * f.w11;
+    r.y = ((s_srgb[(t[0] >> 8) & 255u] * f.w00 + s_srgb[(t[1] >> 8) & 255u] * f.w10) + s_srgb[(t[2] >> 8) & 255u] * f.w01) + s_srgb[(t[3] >> 8) & 255u] * f.w11;
+    r.z = ((s_srgb[(t[0] >> 16) & 255u] * f.w00 + s_srgb[(t[1] >> 16) & 255u] * f.w10) + s_srgb[(t[2] >> 16) & 255u] * f.w01) + s_srgb[(t[3] >> 16) & 255u] * f.w11;
+  } else {
+    const float k = 1.0f / 255.0f;
+    r.x = ((((float)(t[0] & 255u) * f.w00 + (float)(t[1] & 255u) * f.w10) + (float)(t[2] & 255u) * f.w01) + (float)(t[3] & 255u) * f.w11) * k;
+    r.y = ((((float)((t[0] >> 8) & 255u) * f.w00 + (float)((t[1] >> 8) & 255u) * f.w10) + (float)((t[2] >> 8) & 255u) * f.w01) + (float)((t[3] >> 8) & 255u) * f.w11) * k;
+    r.z = ((((float)((t[0] >> 16) & 255u) * f.w00 + (float)((t[1] >> 16) & 255u) * f.w10) + (float)((t[2] >> 16) & 255u) * f.w01) + (float)((t[3] >> 16) & 255u) * f.w11) * k;
+  }
+  if (f.nan) { const float n = __int_as_float(0x7fc00000); r = v3(n, n, n); }
+  return r;
+}
+
+PBR_DEV void load4(const uint32_t* base, const Footprint& f, uint32_t t[4]) { t[0] = base[f.o00]; t[1] = base[f.o10]; t[2] = base[f.o01]; t[3] = base[f.o11]; }
+
+// shader.wgsl:101-105, :111, :148 from an already fetched normal-map sample.
+PBR_DEV void tbn_reflect(const FrameParams* p, const V3& T, const Varyings& v, V3 ns, V3& normal, V3& view_dir, V3& R) {
+  const V3 tn = v3(ns.x * 2.0f - 1.0f, ns.y * 2.0f - 1.0f, ns.z * 2.0f - 1.0f);
+  const V3 N = normalize_fast(v.normal);
+  const V3 B = -normalize_fast(cross(N, T));
+  normal = normalize_fast(T * tn.x + B * tn.y + N * tn.z);
+  view_dir = normalize_fast(v3(p->u.view_pos[0], p->u.view_pos[1], p->u.view_pos[2]) - v.pos);
+  const V3 I = -view_dir;
+  const V3 r = I - normal * (2.0f * dot(normal, I));
+  R = v3(r.x, r.y, -r.z);
+}
+
+__global__ void __launch_bounds__(256) resolve_surface_fast_kernel(const FrameParams* __restrict__ p, ResolveInputs in, const float* __restrict__ srgb_lut,
+                                                                   const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8) {
+  __shared__ float s_srgb[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 3, quad = lane >> 2;
+  const int qx = blockIdx.x * 32 + quad * 2, qy = p->y0 + blockIdx.y * 8 + wave * 2;
+  const int x = qx + (sub & 1), y = qy + (sub >> 1);
   const bool live = x < p->W && y < p->y1;
-  uint32_t id = 0;
-  size_t o = 0;
-  if (live) { o = (size_t)(y - p->y0) * p->W + x; id = vis[o]; }
-  if (live) rgba8[o] = id ? shade_surface(p, in, id - 1u, x, y, s_srgb) : shade_sky(p, in.sky, x, y);
-  const unsigned long long m = __ballot(live && id != 0u);
-  if (covered && (threadIdx.x & 63) == 0 && m) atomicAdd(covered, (uint32_t)__popcll(m));
+  const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
+  const uint32_t id = live ? vis[o] : 0u;                                       // round 1
+  if (__syncthreads_or(id != 0u) == 0) return;
+  s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
+  __syncthreads();
+  if (__ballot(id != 0u) == 0ull) return;
+  const int qbase = lane & ~3;
+  const uint32_t id0 = __shfl(id, qbase), id1 = __shfl(id, qbase + 1), id2 = __shfl(id, qbase + 2);
+  const bool need_explicit = id != 0u && !(id0 == id && id1 == id && id2 == id);
+  const bool any_explicit = __any(need_explicit);
+  const bool cov = id != 0u;
+
+  // rounds 2 and 3: indices, then the three vertices (background lanes read triangle 0; their results are unused)
+  uint32_t inst = 0, tri = cov ? id - 1u : 0u;
+  if (p->n_instances > 1) { inst = tri / (uint32_t)p->n_tris; tri -= inst * (uint32_t)p->n_tris; }
+  const VertexOut* vb = in.vout + (size_t)inst * p->n_verts;
+  const uint32_t i0 = in.indices[3 * tri], i1 = in.indices[3 * tri + 1], i2 = in.indices[3 * tri + 2];
+  const VertexOut v0 = vb[i0], v1 = vb[i1], v2 = vb[i2];
+  Tri t;
+  t.c0 = v0.clip; t.c1 = v1.clip; t.c2 = v2.clip;
+  t.p0 = v3(v0.world_u.x, v0.world_u.y, v0.world_u.z); t.p1 = v3(v1.world_u.x, v1.world_u.y, v1.world_u.z); t.p2 = v3(v2.world_u.x, v2.world_u.y, v2.world_u.z);
+  t.n0 = v3(v0.nrm_v.x, v0.nrm_v.y, v0.nrm_v.z); t.n1 = v3(v1.nrm_v.x, v1.nrm_v.y, v1.nrm_v.z); t.n2 = v3(v2.nrm_v.x, v2.nrm_v.y, v2.nrm_v.z);
+  t.t0 = make_float2(v0.world_u.w, v0.nrm_v.w); t.t1 = make_float2(v1.world_u.w, v1.nrm_v.w); t.t2 = make_float2(v2.world_u.w, v2.nrm_v.w);
+  const QuadBary qb = quad_bary(t, qx, qy, p->W, p->H);
+  const Varyings h0 = varyings_at(t, qb, qx, qy, 0, 0, p->W, p->H), h1 = varyings_at(t, qb, qx, qy, 1, 0, p->W, p->H),
+                 h2 = varyings_at(t, qb, qx, qy, 0, 1, p->W, p->H);
+  const Varyings f = sub == 0 ? h0 : sub == 1 ? h1 : sub == 2 ? h2 : varyings_at(t, qb, qx, qy, 1, 1, p->W, p->H);
+  // quad-shared derivatives (shader.wgsl:97-102)
+  const V3 q1 = h1.pos - h0.pos, q2 = h2.pos - h0.pos;
+  const float2 duvdx = make_float2(h1.uv.x - h0.uv.x, h1.uv.y - h0.uv.y), duvdy = make_float2(h2.uv.x - h0.uv.x, h2.uv.y - h0.uv.y);
+  const V3 T = normalize_fast(q1 * duvdy.y - q2 * duvdx.y);
+  const DevTex8& tx0 = in.tex[0];
+  const int level = lod_2d(tx0.w, tx0.h, p->u.use_mipmaps ? tx0.levels : 1, 15u, duvdx, duvdy).level;
+
+  // round 4: every material texel of this pixel, and the normal-map texels of the helper pixels
+  const Footprint fp = footprint_fast(tx0, level, f.uv.x, f.uv.y);
+  uint32_t t_nrm[4], t_mr[4], t_alb[4], t_emi[4], t_occ[4], t_h0[4], t_h1[4], t_h2[4];
+  load4(in.tex[PBR_TEX_NORMAL].base, fp, t_nrm);
+  load4(in.tex[PBR_TEX_METALLIC_ROUGHNESS].base, fp, t_mr);
+  load4(in.tex[PBR_TEX_ALBEDO].base, fp, t_alb);
+  load4(in.tex[PBR_TEX_EMISSIVE].base, fp, t_emi);
+  load4(in.tex[PBR_TEX_OCCLUSION].base, fp, t_occ);
+  Footprint fp0 = fp, fp1 = fp, fp2 = fp;
+  if (any_explicit) {
+    fp0 = footprint_fast(tx0, level, h0.uv.x, h0.uv.y); fp1 = footprint_fast(tx0, level, h1.uv.x, h1.uv.y); fp2 = footprint_fast(tx0, level, h2.uv.x, h2.uv.y);
+    load4(in.tex[PBR_TEX_NORMAL].base, fp0, t_h0); load4(in.tex[PBR_TEX_NORMAL].base, fp1, t_h1); load4(in.tex[PBR_TEX_NORMAL].base, fp2, t_h2);
+  }
+
+  V3 normal, view_dir, R;
+  tbn_reflect(p, T, f, decode_fast<false>(t_nrm, fp, s_srgb), normal, view_dir, R);
+  V3 R0 = shfl3(R, qbase), R1 = shfl3(R, qbase + 1), R2 = shfl3(R, qbase + 2);
+  if (any_explicit && need_explicit) {
+    V3 n_, v_;
+    tbn_reflect(p, T, h0, decode_fast<false>(t_h0, fp0, s_srgb), n_, v_, R0);
+    tbn_reflect(p, T, h1, decode_fast<false>(t_h1, fp1, s_srgb), n_, v_, R1);
+    tbn_reflect(p, T, h2, decode_fast<false>(t_h2, fp2, s_srgb), n_, v_, R2);
+  }
+  const float ndotv = fmaxf(dot(normal, view_dir), 0.0f);
+  const V3 mr = decode_fast<false>(t_mr, fp, s_srgb);
+  const float metalness = mr.z, roughness = mr.y;
+
+  // round 5: irradiance (one level), prefilter (two levels of the implicit LOD), BRDF table
+  float lambda = cube_lambda(in.pre.size, R, R1 - R0, R2 - R0);
+  if (isnan(lambda)) lambda = 0.0f;
+  lambda = fminf(fmaxf(lambda, 0.0f), (float)(in.pre.levels - 1));
+  const int l0 = (int)floorf(lambda), l1 = min(l0 + 1, in.pre.levels - 1);
+  const float lf = lambda - (float)l0;
+  const V3 nd = v3(normal.x, normal.y, -normal.z);
+  const bool bad_n = any_nan(nd), bad_r = any_nan(R);
+  const CubeCoord cn = cube_select(bad_n ? v3(0, 0, 1) : nd), cr = cube_select(bad_r ? v3(0, 0, 1) : R);
+  const CubeFoot fi = cube_foot(in.irr, 0, cn), fa = cube_foot(in.pre, l0, cr), fb = cube_foot(in.pre, l1, cr);
+  const int ls = in.lut_size;
+  const float lu = ndotv * (float)ls - 0.5f, lv = roughness * (float)ls - 0.5f;
+  const float lfu = floorf(lu), lfv = floorf(lv), la = lu - lfu, lb = lv - lfv;
+  int lx0 = (int)lfu, ly0 = (int)lfv, lx1 = lx0 + 1, ly1 = ly0 + 1;
+  const bool bad_lut = isnan(lu) || isnan(lv);
+  if ((ls & (ls - 1)) == 0) { lx0 &= ls - 1; lx1 &= ls - 1; ly0 &= ls - 1; ly1 &= ls - 1; }
+  else { lx0 = ((lx0 % ls) + ls) % ls; lx1 = ((lx1 % ls) + ls) % ls; ly0 = ((ly0 % ls) + ls) % ls; ly1 = ((ly1 % ls) + ls) % ls; }
+  if (bad_lut) { lx0 = lx1 = ly0 = ly1 = 0; }
+  float4 ti[4], ta[4], tb[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { ti[k] = in.irr.base[fi.o[k]]; ta[k] = in.pre.base[fa.o[k]]; tb[k] = in.pre.base[fb.o[k]]; }
+  const ushort4* lt = reinterpret_cast<const ushort4*>(in.lut);
+  const ushort4 u00 = lt[(uint32_t)ly0 * ls + lx0], u10 = lt[(uint32_t)ly0 * ls + lx1], u01 = lt[(uint32_t)ly1 * ls + lx0], u11 = lt[(uint32_t)ly1 * ls + lx1];
+
+  // the rest of fs_main (shader.wgsl:95, :108-159)
+  const V3 albedo = decode_fast<true>(t_alb, fp, s_srgb);
+  const V3 em = decode_fast<true>(t_emi, fp, s_srgb);
+  const V3 emissive = v3(em.x * p->u.emissive_factor[0], em.y * p->u.emissive_factor[1], em.z * p->u.emissive_factor[2]);
+  const float occlusion = decode_fast<false>(t_occ, fp, s_srgb).x;
+  const float om = 1.0f - metalness;
+  const V3 f0 = v3(0.04f * om + albedo.x * metalness, 0.04f * om + albedo.y * metalness, 0.04f * om + albedo.z * metalness);
+  V3 Lo = v3(0, 0, 0);
+  const float a = roughness * roughness, a2 = a * a;
+  const float rk = roughness + 1.0f, k = (rk * rk) * 0.125f;
+  const float g_v = smith_ggx(ndotv, k);
+  const float inv_pi = 1.0f / PI_F;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const V3 to_light = v3(p->u.light_pos[i][0], p->u.light_pos[i][1], p->u.light_pos[i][2]) - f.pos;
+    const float dist2 = dot(to_light, to_light), inv_dist = rsq_fast(dist2);
+    const V3 light_dir = to_light * inv_dist;
+    const V3 halfway = normalize_fast(view_dir + light_dir);
+    const float ndoth = fmaxf(dot(normal, halfway), 0.0f);
+    float denom = ndoth * ndoth * (a2 - 1.0f) + 1.0f;
+    denom = PI_F * denom * denom;
+    const float D = a2 * rcp_fast(denom);
+    const float fcw = pow5(clamp01(1.0f - fmaxf(dot(halfway, view_dir), 0.0f)));
+    const V3 F = v3(f0.x + (1.0f - f0.x) * fcw, f0.y + (1.0f - f0.y) * fcw, f0.z + (1.0f - f0.z) * fcw);
+    const float ndotl = fmaxf(dot(normal, light_dir), 0.0f);
+    const float dg = D * (g_v * smith_ggx(ndotl, k)) * rcp_fast(4.0f * ndotv * ndotl + 0.001f);
+    const float sc = (inv_dist * inv_dist) * ndotl;
+    Lo.x += ((1.0f - F.x) * om * albedo.x * inv_pi + dg * F.x) * (p->u.light_color[i][0] * sc);
+    Lo.y += ((1.0f - F.y) * om * albedo.y * inv_pi + dg * F.y) * (p->u.light_color[i][1] * sc);
+    Lo.z += ((1.0f - F.z) * om * albedo.z * inv_pi + dg * F.z) * (p->u.light_color[i][2] * sc);
+  }
+  const float fcw = pow5(clamp01(1.0f - ndotv));
+  const float omr = 1.0f - roughness;
+  const V3 kS = v3(f0.x + (fmaxf(omr, f0.x) - f0.x) * fcw, f0.y + (fmaxf(omr, f0.y) - f0.y) * fcw, f0.z + (fmaxf(omr, f0.z) - f0.z) * fcw);
+  const V3 kD = v3((1.0f - kS.x) * om, (1.0f - kS.y) * om, (1.0f - kS.z) * om);
+  const float nanv = __int_as_float(0x7fc00000);
+  V3 irr = weigh4(ti, fi.w);
+  if (bad_n) irr = v3(nanv, nanv, nanv);
+  const V3 pa = weigh4(ta, fa.w), pb = weigh4(tb, fb.w);
+  V3 pf = (lf == 0.0f || l1 == l0) ? pa : v3(pa.x * (1.0f - lf) + pb.x * lf, pa.y * (1.0f - lf) + pb.y * lf, pa.z * (1.0f - lf) + pb.z * lf);
+  if (bad_r) pf = v3(nanv, nanv, nanv);
+  const float w00 = (1.0f - la) * (1.0f - lb), w10 = la * (1.0f - lb), w01 = (1.0f - la) * lb, w11 = la * lb;
+  // NaN texels (column 0 of the table) poison the result even at zero weight: 0 * NaN = NaN
+  float bx = ((__half2float(__ushort_as_half(u00.x)) * w00 + __half2float(__ushort_as_half(u10.x)) * w10) + __half2float(__ushort_as_half(u01.x)) * w01) +
+             __half2float(__ushort_as_half(u11.x)) * w11;
+  float by = ((__half2float(__ushort_as_half(u00.y)) * w00 + __half2float(__ushort_as_half(u10.y)) * w10) + __half2float(__ushort_as_half(u01.y)) * w01) +
+             __half2float(__ushort_as_half(u11.y)) * w11;
+  if (bad_lut) { bx = nanv; by = nanv; }
+  const V3 specular = v3(pf.x * (kS.x * bx + by), pf.y * (kS.y * bx + by), pf.z * (kS.z * bx + by));
+  const V3 ambient = v3((kD.x * irr.x * albedo.x + specular.x) * occlusion, (kD.y * irr.y * albedo.y + specular.y) * occlusion,
+                        (kD.z * irr.z * albedo.z + specular.z) * occlusion);
+  if (cov) rgba8[o] = pack_color(v3(ambient.x + Lo.x + emissive.x, ambient.y + Lo.y + emissive.y, ambient.z + Lo.z + emissive.z));
+}
+
+// Background pixels: fs_main of skybox.wgsl:24-33.  One thread shades four horizontally adjacent
+// pixels: one 16-byte visibility read, sixteen independent cube taps in flight, one 16-byte store.
+__global__ void __launch_bounds__(256) resolve_sky_kernel(const FrameParams* __restrict__ p, DevCube sky, const uint32_t* __restrict__ vis,
+                                                          uint32_t* __restrict__ rgba8) {
+  const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = p->y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int W = p->W;
+  if (x0 >= W || y >= p->y1) return;
+  const size_t o = (size_t)(y - p->y0) * W + x0;
+  const bool wide = x0 + 3 < W && (o & 3) == 0;
+  uint32_t id[4] = {1u, 1u, 1u, 1u};
+  if (wide) { const uint4 v = *reinterpret_cast<const uint4*>(vis + o); id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w; }
+  else { for (int k = 0; k < 4; ++k) if (x0 + k < W) id[k] = vis[o + k]; }
+  if (id[0] && id[1] && id[2] && id[3]) return;
+  const float* m = p->u.inv_view_proj;
+  const float yn = 1.0f - ((float)y + 0.5f) / (float)p->H * 2.0f;
+  CubeFoot foot[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float xn = ((float)(x0 + k) + 0.5f) / (float)W * 2.0f - 1.0f;
+    const float tx = ((m[0] * xn + m[4] * yn) + m[8]) + m[12];
+    const float ty = ((m[1] * xn + m[5] * yn) + m[9]) + m[13];
+    const float tz = ((m[2] * xn + m[6] * yn) + m[10]) + m[14];
+    const float tw = ((m[3] * xn + m[7] * yn) + m[11]) + m[15];
+    // normalize(xyz / w) only rescales the lookup direction by 1 / (w |xyz|); the cube lookup depends on
+    // the direction alone, so only the sign of w is applied.
+    const float sg = tw < 0.0f ? -1.0f : 1.0f;
+    foot[k] = cube_foot(sky, 0, cube_select(v3(tx * sg, ty * sg, -(tz * sg))));
+  }
+  float4 tap[4][4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tap[k][j] = sky.base[foot[k].o[j]];
+  uint32_t out[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = pack_color(weigh4(tap[k], foot[k].w));
+  if (wide && !(id[0] | id[1] | id[2] | id[3])) { *reinterpret_cast<uint4*>(rgba8 + o) = make_uint4(out[0], out[1], out[2], out[3]); return; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (x0 + k < W && !id[k]) rgba8[o + k] = out[k];
+}
+
+// Number of covered pixels, for the frame statistics only: one atomic per 16384 pixels (a single
+// counter sustains under a hundred atomics per microsecond, so it must not sit in the resolve).
+__global__ void __launch_bounds__(256) count_covered_kernel(const uint32_t* __restrict__ vis, size_t n, uint32_t* __restrict__ covered) {
+  __shared__ uint32_t s_part[4];
+  uint32_t c = 0;
+  const size_t begin = (size_t)blockIdx.x * 16384;
+  for (size_t i = begin + threadIdx.x; i < begin + 16384 && i < n; i += 256) c += vis[i] != 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) { const uint32_t t = s_part[0] + s_part[1] + s_part[2] + s_part[3]; if (t) atomicAdd(covered, t); }
 }
 
 }  // namespace
 
 void launch_resolve(hipStream_t s, const FrameParams* p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    uint32_t* covered, int W, int rows) {
+                    int W, int rows, bool fast) {
+  uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
+  hipLaunchKernelGGL(resolve_sky_kernel, dim3((W + 255) / 256, (rows + 3) / 4), dim3(256), 0, s, p, in.sky, vis, out);
   dim3 grid((W + 31) / 32, (rows + 7) / 8);
-  hipLaunchKernelGGL(resolve_kernel, grid, dim3(256), 0, s, p, in, srgb_lut, vis, reinterpret_cast<uint32_t*>(rgba8), covered);
+  if (fast)
+    hipLaunchKernelGGL(resolve_surface_fast_kernel, grid, dim3(256), 0, s, p, in, srgb_lut, vis, out);
+  else
+    hipLaunchKernelGGL(resolve_surface_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis, out);
+}
+
+void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered) {
+  hipLaunchKernelGGL(count_covered_kernel, dim3((unsigned)((n + 16383) / 16384)), dim3(256), 0, s, vis, n, covered);
 }
