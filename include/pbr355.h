@@ -74,7 +74,7 @@ typedef struct PbrFrameStats {
   float ms_resolve;     /* deferred shading resolve */
   float ms_total;       /* first launch to last completion */
   uint32_t covered_pixels;   /* pixels whose visibility entry is a triangle */
-  uint32_t binned_refs;      /* triangle-tile references produced by binning */
+  uint32_t binned_refs;      /* triangle-tile references that spilled past a tile's own bin row */
   uint32_t setup_triangles;  /* front-facing (sub)triangles after clipping and culling */
   uint32_t reserved;
 } PbrFrameStats;

@@ -143,19 +143,18 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
   const size_t want_setup = ntri + ntri / 4 + 4096;
   if (want_setup > c->setup_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_dev(c->d_setup); free_dev(c->d_bin_list);
+    free_dev(c->d_setup); free_dev(c->d_overflow);
     HIP_TRY(c, hipMalloc(&c->d_setup, want_setup * sizeof(SetupTri)));
     c->setup_cap = want_setup;
-    c->bin_cap = want_setup * 8 + (1u << 20);
-    HIP_TRY(c, hipMalloc(&c->d_bin_list, c->bin_cap * sizeof(uint32_t)));
+    c->overflow_cap = want_setup * 2 + (1u << 16);
+    HIP_TRY(c, hipMalloc(&c->d_overflow, c->overflow_cap * sizeof(uint2)));
     grew = true;
   }
   if ((size_t)n_tiles > c->tile_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_dev(c->d_tile_count); free_dev(c->d_tile_offset); free_dev(c->d_tile_cursor);
+    free_dev(c->d_tile_count); free_dev(c->d_bins);
     HIP_TRY(c, hipMalloc(&c->d_tile_count, sizeof(uint32_t) * n_tiles));
-    HIP_TRY(c, hipMalloc(&c->d_tile_offset, sizeof(uint32_t) * n_tiles));
-    HIP_TRY(c, hipMalloc(&c->d_tile_cursor, sizeof(uint32_t) * n_tiles));
+    HIP_TRY(c, hipMalloc(&c->d_bins, sizeof(uint32_t) * (size_t)n_tiles * PBR_BIN_CAP));
     HIP_TRY(c, hipMemset(c->d_tile_count, 0, sizeof(uint32_t) * n_tiles));   // kept clear from frame to frame by the raster kernel
     c->tile_cap = n_tiles; grew = true;
   }
@@ -206,7 +205,7 @@ static int check_sticky(PbrContext* c) {
     uint32_t code = c->h_counters[2];
     c->h_counters[2] = 0;
     (void)hipMemset(&c->d_counters[2], 0, sizeof(uint32_t));
-    return fail(c, PBR_E_STATE, code == 1 ? "triangle setup buffer overflow" : "tile bin list overflow");
+    return fail(c, PBR_E_STATE, code == 1 ? "triangle setup buffer overflow" : "tile bin overflow list full");
   }
   return PBR_OK;
 }
@@ -253,14 +252,14 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], s));
   if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames], s));
 
-  launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances);
+  launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
-  launch_setup_and_bin(s, dp, c->d_vout, c->d_indices, c->d_setup, (uint32_t)c->setup_cap, c->d_tile_count, c->d_tile_offset, c->d_tile_cursor,
-                       c->d_bin_list, (uint32_t)c->bin_cap, c->d_counters, c->n_indices / 3, c->n_instances, tiles_x * tiles_y);
+  launch_setup_and_bin(s, dp, c->d_vout, c->d_indices, c->d_setup, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
+                       (uint32_t)c->overflow_cap, c->d_counters, c->n_indices / 3, c->n_instances);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
-  launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_tile_offset, c->d_bin_list, vis, c->capture_depth ? c->d_depth : nullptr, c->d_counters, tiles_x,
-                tiles_y);
+  launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
+                c->d_counters, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
   if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames + 1], s));
 
@@ -293,8 +292,8 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     (void)hipEventElapsedTime(&stats->ms_raster, c->ev[2], c->ev[3]);
     (void)hipEventElapsedTime(&stats->ms_resolve, c->ev[3], c->ev[4]);
     (void)hipEventElapsedTime(&stats->ms_total, c->ev[0], c->ev[4]);
-    stats->setup_triangles = c->h_counters[4];
-    stats->binned_refs = c->h_counters[5];
+    stats->setup_triangles = c->h_counters[0];
+    stats->binned_refs = c->h_counters[1];   // references that spilled past a tile's own row
     stats->covered_pixels = c->h_counters[3];
     stats->reserved = 0;
     return check_sticky(c);
@@ -356,8 +355,8 @@ int pbr_destroy(PbrContext* c) {
   for (auto& t : c->d_tex) free_dev(t);
   free_dev(c->d_hdr); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
-  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_tile_count); free_dev(c->d_tile_offset); free_dev(c->d_tile_cursor);
-  free_dev(c->d_bin_list); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
+  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_tile_count); free_dev(c->d_bins);
+  free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
   free_dev(pr->ring.dev); free_dev(pr->d_srgb_lut);
   if (pr->ring.host) (void)hipHostFree(pr->ring.host);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
@@ -697,7 +696,7 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   fp.W = 32; fp.H = 32; fp.y0 = 0; fp.y1 = 32; fp.tiles_x = 1; fp.tiles_y = 1;
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances; fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
   HIP_TRY(c, hipMemcpy(pr->ring.dev, &fp, sizeof fp, hipMemcpyHostToDevice));
-  launch_vertex_stage(c->stream, pr->ring.dev, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances);
+  launch_vertex_stage(c->stream, pr->ring.dev, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const size_t nv = (size_t)c->n_verts * c->n_instances;
   std::vector<VertexOut> host(nv);

@@ -11,6 +11,7 @@
 #define PBR_SUBPIXEL_BITS 8
 #define PBR_GUARD 8.0f            // guard band in units of w
 #define PBR_PREFILTER_SAMPLES 1024
+#define PBR_BIN_CAP 256           // triangle references a tile keeps in its own row before spilling to the overflow list
 
 // An rgba8 texture with its mip chain in one allocation.
 struct DevTex8 {
@@ -99,9 +100,9 @@ struct PbrContext {
   // frame working set (grown on demand)
   VertexOut* d_vout = nullptr;    size_t vout_cap = 0;
   SetupTri* d_setup = nullptr;    size_t setup_cap = 0;
-  uint32_t* d_tile_count = nullptr; uint32_t* d_tile_offset = nullptr; uint32_t* d_tile_cursor = nullptr; size_t tile_cap = 0;
-  uint32_t* d_bin_list = nullptr; size_t bin_cap = 0;
-  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [4] [5] last frame's [0] [1]
+  uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0;   // [tiles], [tiles][PBR_BIN_CAP]
+  uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
+  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, 
   bool capture_depth = false;
   uint32_t* h_counters = nullptr; // pinned mirror
   uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0;
@@ -126,12 +127,12 @@ void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* sam
 void launch_brdf_lut(hipStream_t s, uint16_t* out, int size);
 
 void launch_vertex_stage(hipStream_t s, const FrameParams* p, const float* vsoa, const float* inst_model, const float* inst_normal,
-                         VertexOut* out, int n_verts, int n_instances);
+                         VertexOut* out, uint32_t* counters, int n_verts, int n_instances);
 void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
-                          uint32_t setup_cap, uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* bin_list,
-                          uint32_t bin_cap, uint32_t* counters, int n_tris, int n_instances, int n_tiles);
-void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* tile_offset,
-                   const uint32_t* bin_list, uint32_t* vis, float* depth, uint32_t* counters, int tiles_x, int tiles_y);
+                          uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
+                          int n_tris, int n_instances);
+void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, const uint32_t* counters, int tiles_x, int tiles_y);
 struct ResolveInputs {
   const VertexOut* vout;
   const uint16_t* indices;

@@ -20,9 +20,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) vertex_kernel(const FrameParams* __restrict__ p, const float* __restrict__ vsoa,
                                                      const float* __restrict__ inst_model, const float* __restrict__ inst_normal,
-                                                     VertexOut* __restrict__ out, int n_verts) {
+                                                     VertexOut* __restrict__ out, uint32_t* __restrict__ counters, int n_verts) {
   const int inst = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
+  // first kernel of a frame: re-arm the setup-triangle and bin-overflow counters the later kernels append with
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { counters[0] = 0u; counters[1] = 0u; }
   if (i >= n_verts) return;
   float model[16], nmat[16], pvm[16];
   const float* msrc = p->has_instance_mats ? inst_model + 16 * inst : p->u.model;
@@ -84,8 +86,47 @@ PBR_DEV bool setup_bounds(const SetupTri& t, const FrameParams* p, TileBox& box)
   return true;
 }
 
-PBR_DEV void emit_triangle(uint32_t id, float4 a, float4 b, float4 c, const FrameParams* p, SetupTri* setup, uint32_t setup_cap,
-                           uint32_t* tile_count, uint32_t* counters) {
+// Appends a front-facing (sub)triangle to the setup list and references it from every tile its
+// bounding box touches.  A tile keeps its first PBR_BIN_CAP references in its own row of `bins`;
+// any beyond that go to one shared overflow list of (tile, triangle) pairs.
+struct BinTargets {
+  SetupTri* setup; uint32_t setup_cap;
+  uint32_t* tile_count; uint32_t* bins;
+  uint2* overflow; uint32_t overflow_cap;
+  uint32_t* counters;
+};
+
+PBR_DEV void bin_store(const BinTargets& bt, uint32_t tile, uint32_t pos, uint32_t slot) {
+  if (pos < PBR_BIN_CAP) bt.bins[(size_t)tile * PBR_BIN_CAP + pos] = slot;
+  else {
+    const uint32_t o = atomicAdd(&bt.counters[1], 1u);
+    if (o < bt.overflow_cap) bt.overflow[o] = make_uint2(tile, slot); else bt.counters[2] = 2u;
+  }
+}
+PBR_DEV void bin_reference(const FrameParams* p, const BinTargets& bt, uint32_t tile, uint32_t slot) {
+  bin_store(bt, tile, atomicAdd(&bt.tile_count[tile], 1u), slot);
+}
+// References tiles [first, first + 4) of a bounding box, in row-major order: the four position
+// atomics are issued back to back so that their latencies overlap, then the four stores follow.
+PBR_DEV void bin_four(const FrameParams* p, const BinTargets& bt, int tx0, int ty0, int bw, int n, int first, uint32_t slot) {
+  uint32_t tile[4], pos[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = first + k;
+    const int row = bw == 1 ? i : bw == 2 ? i >> 1 : i / bw;
+    tile[k] = (uint32_t)((ty0 + row) * p->tiles_x + tx0 + (i - row * bw));
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (first + k < n) pos[k] = atomicAdd(&bt.tile_count[tile[k]], 1u);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (first + k < n) bin_store(bt, tile[k], pos[k], slot);
+}
+
+// A triangle whose bounding box spans more than sixteen tiles is not binned by its own thread (a
+// chain of dependent atomics); it is handed back so that the whole wavefront can bin it, one tile per lane.
+struct Deferred { uint32_t slot; int box; };   // box = tx0 | tx1 << 8 | ty0 << 16 | ty1 << 24, slot 0xffffffff = none
+
+PBR_DEV void emit_triangle(uint32_t id, float4 a, float4 b, float4 c, const FrameParams* p, const BinTargets& bt, Deferred* defer) {
   Snapped s0 = snap_vertex(a, p->W, p->H), s1 = snap_vertex(b, p->W, p->H), s2 = snap_vertex(c, p->W, p->H);
   const long long area2 = (long long)(s1.X - s0.X) * (s2.Y - s0.Y) - (long long)(s2.X - s0.X) * (s1.Y - s0.Y);
   if (area2 >= 0) return;   // clockwise on screen or degenerate: culled (cullMode "back", frontFace "ccw")
@@ -96,19 +137,20 @@ PBR_DEV void emit_triangle(uint32_t id, float4 a, float4 b, float4 c, const Fram
   t.id = id; t.pad = 0;
   TileBox box;
   if (!setup_bounds(t, p, box)) return;
-  const uint32_t slot = atomicAdd(&counters[0], 1u);
-  if (slot >= setup_cap) { counters[2] = 1u; return; }
-  setup[slot] = t;
-  for (int ty = box.ty0; ty <= box.ty1; ++ty)
-    for (int tx = box.tx0; tx <= box.tx1; ++tx) atomicAdd(&tile_count[ty * p->tiles_x + tx], 1u);
+  const uint32_t slot = atomicAdd(&bt.counters[0], 1u);
+  if (slot >= bt.setup_cap) { bt.counters[2] = 1u; return; }
+  bt.setup[slot] = t;
+  const int n_tiles = (box.tx1 - box.tx0 + 1) * (box.ty1 - box.ty0 + 1);
+  if (defer && n_tiles > 16 && box.tx1 < 256 && box.ty1 < 256) {
+    defer->slot = slot; defer->box = box.tx0 | (box.tx1 << 8) | (box.ty0 << 16) | (box.ty1 << 24);
+    return;
+  }
+  const int bw = box.tx1 - box.tx0 + 1;
+  for (int first = 0; first < n_tiles; first += 4) bin_four(p, bt, box.tx0, box.ty0, bw, n_tiles, first, slot);
 }
 
-__global__ void __launch_bounds__(256) setup_kernel(const FrameParams* __restrict__ p, const VertexOut* __restrict__ vout,
-                                                    const uint16_t* __restrict__ indices, SetupTri* __restrict__ setup, uint32_t setup_cap,
-                                                    uint32_t* __restrict__ tile_count, uint32_t* __restrict__ counters, int n_tris) {
-  const int inst = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= n_tris) return;
+PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint16_t* indices, const BinTargets& bt, int inst, int t, int n_tris,
+                       Deferred* defer) {
   const size_t base = (size_t)inst * p->n_verts;
   const float4 a = vout[base + indices[3 * t]].clip, b = vout[base + indices[3 * t + 1]].clip, c = vout[base + indices[3 * t + 2]].clip;
   const uint32_t id = (uint32_t)inst * (uint32_t)n_tris + (uint32_t)t;
@@ -123,12 +165,12 @@ __global__ void __launch_bounds__(256) setup_kernel(const FrameParams* __restric
     if (outside) inside_all = false;
   }
   {
-    int l = 0, r = 0, bt = 0, tp = 0;
+    int l = 0, r = 0, bt_ = 0, tp = 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { l += v[k].x < -v[k].w; r += v[k].x > v[k].w; bt += v[k].y < -v[k].w; tp += v[k].y > v[k].w; }
-    if (l == 3 || r == 3 || bt == 3 || tp == 3) return;   // beside the viewport: no pixel centre can be covered
+    for (int k = 0; k < 3; ++k) { l += v[k].x < -v[k].w; r += v[k].x > v[k].w; bt_ += v[k].y < -v[k].w; tp += v[k].y > v[k].w; }
+    if (l == 3 || r == 3 || bt_ == 3 || tp == 3) return;   // beside the viewport: no pixel centre can be covered
   }
-  if (inside_all) { emit_triangle(id, a, b, c, p, setup, setup_cap, tile_count, counters); return; }
+  if (inside_all) { emit_triangle(id, a, b, c, p, bt, defer); return; }
   // Rare path: Sutherland-Hodgman against the six planes, then a fan from the first vertex.
   float4 poly[12], tmp[12];
   int n = 3;
@@ -148,47 +190,28 @@ __global__ void __launch_bounds__(256) setup_kernel(const FrameParams* __restric
     n = m;
     for (int k = 0; k < n; ++k) poly[k] = tmp[k];
   }
-  for (int k = 1; k + 1 < n; ++k) emit_triangle(id, poly[0], poly[k], poly[k + 1], p, setup, setup_cap, tile_count, counters);
+  for (int k = 1; k + 1 < n; ++k) emit_triangle(id, poly[0], poly[k], poly[k + 1], p, bt, nullptr);
 }
 
-// Exclusive scan of the per-tile counts by one workgroup: each thread scans a contiguous chunk,
-// the chunk totals are scanned through LDS.
-__global__ void __launch_bounds__(1024) tile_scan_kernel(const uint32_t* __restrict__ count, uint32_t* __restrict__ offset,
-                                                         uint32_t* __restrict__ cursor, uint32_t* __restrict__ counters, int n) {
-  __shared__ uint32_t s_sum[1024];
-  const int tid = threadIdx.x;
-  const int chunk = (n + 1023) / 1024;
-  const int begin = tid * chunk, end = min(begin + chunk, n);
-  uint32_t sum = 0;
-  for (int i = begin; i < end; ++i) sum += count[i];
-  s_sum[tid] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    uint32_t v = tid >= d ? s_sum[tid - d] : 0u;
-    __syncthreads();
-    s_sum[tid] += v;
-    __syncthreads();
+__global__ void __launch_bounds__(256) setup_kernel(const FrameParams* __restrict__ p, const VertexOut* __restrict__ vout,
+                                                    const uint16_t* __restrict__ indices, BinTargets bt, int n_tris) {
+  const int inst = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  Deferred d;
+  d.slot = 0xffffffffu; d.box = 0;
+  if (t < n_tris) setup_one(p, vout, indices, bt, inst, t, n_tris, &d);
+  // wave-cooperative binning of the triangles that span many tiles: one tile per lane
+  unsigned long long todo = __ballot(d.slot != 0xffffffffu);
+  const int lane = threadIdx.x & 63;
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)d.slot, src);
+    const int box = __builtin_amdgcn_readlane(d.box, src);
+    const int tx0 = box & 255, tx1 = (box >> 8) & 255, ty0 = (box >> 16) & 255, ty1 = (box >> 24) & 255;
+    const int bw = tx1 - tx0 + 1, n = bw * (ty1 - ty0 + 1);
+    for (int i = lane; i < n; i += 64) bin_reference(p, bt, (uint32_t)((ty0 + i / bw) * p->tiles_x + tx0 + i % bw), slot);
   }
-  uint32_t run = s_sum[tid] - sum;
-  for (int i = begin; i < end; ++i) { offset[i] = run; cursor[i] = 0u; run += count[i]; }
-  if (tid == 1023) counters[1] = s_sum[1023];
-}
-
-__global__ void __launch_bounds__(256) bin_fill_kernel(const FrameParams* __restrict__ p, const SetupTri* __restrict__ setup, uint32_t setup_cap,
-                                                       const uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_cursor,
-                                                       uint32_t* __restrict__ bin_list, uint32_t bin_cap, uint32_t* __restrict__ counters) {
-  const uint32_t n = min(counters[0], setup_cap);
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const SetupTri t = setup[i];
-  TileBox box;
-  if (!setup_bounds(t, p, box)) return;
-  for (int ty = box.ty0; ty <= box.ty1; ++ty)
-    for (int tx = box.tx0; tx <= box.tx1; ++tx) {
-      const int tile = ty * p->tiles_x + tx;
-      const uint32_t pos = tile_offset[tile] + atomicAdd(&tile_cursor[tile], 1u);
-      if (pos < bin_cap) bin_list[pos] = i; else counters[2] = 2u;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -214,27 +237,25 @@ PBR_DEV long long bcast64(long long v, int src_lane) {
 }
 
 __global__ void __launch_bounds__(256) raster_kernel(const FrameParams* __restrict__ p, const SetupTri* __restrict__ setup,
-                                                     uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_offset,
-                                                     const uint32_t* __restrict__ bin_list, uint32_t* __restrict__ vis, float* __restrict__ depth,
-                                                     uint32_t* __restrict__ counters) {
+                                                     uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
+                                                     const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
+                                                     float* __restrict__ depth, const uint32_t* __restrict__ counters) {
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
   const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px0 = blockIdx.x * PBR_TILE, py0 = p->y0 + blockIdx.y * PBR_TILE;   // tile origin in pixels
-  const uint32_t n = tile_count[tile], base = tile_offset[tile];
+  const uint32_t n = tile_count[tile];
+  // the first PBR_BIN_CAP references sit in the tile's own row; a fuller tile also filters the shared overflow list
+  const uint32_t n_row = min(n, (uint32_t)PBR_BIN_CAP);
+  const uint32_t n_entries = n_row + (n > PBR_BIN_CAP ? min(counters[1], overflow_cap) : 0u);
   const int xmax = min(px0 + PBR_TILE, p->W) - 1, ymax = min(py0 + PBR_TILE, p->y1) - 1;
   const unsigned long long clear_key = (unsigned long long)depth_key(1.0f) << 32;   // depth clear 1.0, no triangle
-
-  if (tile == 0 && tid == 0) {   // hand the frame's counters to the statistics slots and re-arm them for the next frame
-    counters[4] = counters[0]; counters[5] = counters[1];
-    counters[0] = 0u; counters[1] = 0u;
-  }
 
   if (n != 0u) {
     for (int i = tid; i < PBR_TILE * PBR_TILE; i += 256) s_key[i] = clear_key;
     __syncthreads();
     const long long ox = (long long)px0 * 256 + 128, oy = (long long)py0 * 256 + 128;
-    for (uint32_t chunk = 0; chunk < n; chunk += 256) {
+    for (uint32_t chunk = 0; chunk < n_entries; chunk += 256) {
       // lane-parallel: fetch one triangle per lane and set it up against this tile.  Entry
       // chunk + 4*lane + wave goes to this lane, so a short bin is still spread over all four waves.
       bool keep = false;
@@ -243,8 +264,11 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams* __restri
       float z0 = 0, dz1 = 0, dz2 = 0, inv_area = 0;
       uint32_t id = 0;
       const uint32_t entry = chunk + 4u * lane + wave;
-      if (entry < n) {
-        const SetupTri t = setup[bin_list[base + entry]];
+      uint32_t slot = 0xffffffffu;
+      if (entry < n_row) slot = bins[(size_t)tile * PBR_BIN_CAP + entry];
+      else if (entry < n_entries) { const uint2 pr = overflow[entry - n_row]; if (pr.x == (uint32_t)tile) slot = pr.y; }
+      if (slot != 0xffffffffu) {
+        const SetupTri t = setup[slot];
         keep = true;
         long long e[3]; int a[3], b[3];
 #pragma unroll
@@ -356,23 +380,24 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams* __restri
 }  // namespace
 
 void launch_vertex_stage(hipStream_t s, const FrameParams* p, const float* vsoa, const float* inst_model, const float* inst_normal,
-                         VertexOut* out, int n_verts, int n_instances) {
+                         VertexOut* out, uint32_t* counters, int n_verts, int n_instances) {
   dim3 grid((n_verts + 255) / 256, n_instances);
-  hipLaunchKernelGGL(vertex_kernel, grid, dim3(256), 0, s, p, vsoa, inst_model, inst_normal, out, n_verts);
+  hipLaunchKernelGGL(vertex_kernel, grid, dim3(256), 0, s, p, vsoa, inst_model, inst_normal, out, counters, n_verts);
 }
 
 void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
-                          uint32_t setup_cap, uint32_t* tile_count, uint32_t* tile_offset, uint32_t* tile_cursor, uint32_t* bin_list,
-                          uint32_t bin_cap, uint32_t* counters, int n_tris, int n_instances, int n_tiles) {
-  // tile_count and the counters are zero on entry: the raster kernel of the previous frame clears them
+                          uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
+                          int n_tris, int n_instances) {
+  // tile_count is zero on entry (the raster kernel of the previous frame clears it) and the vertex
+  // kernel has reset the append counters
+  BinTargets bt;
+  bt.setup = setup; bt.setup_cap = setup_cap; bt.tile_count = tile_count; bt.bins = bins; bt.overflow = overflow; bt.overflow_cap = overflow_cap;
+  bt.counters = counters;
   dim3 grid((n_tris + 255) / 256, n_instances);
-  hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, s, p, vout, indices, setup, setup_cap, tile_count, counters, n_tris);
-  hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, s, tile_count, tile_offset, tile_cursor, counters, n_tiles);
-  hipLaunchKernelGGL(bin_fill_kernel, dim3((setup_cap + 255) / 256), dim3(256), 0, s, p, setup, setup_cap, tile_offset, tile_cursor, bin_list,
-                     bin_cap, counters);
+  hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, s, p, vout, indices, bt, n_tris);
 }
 
-void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* tile_offset,
-                   const uint32_t* bin_list, uint32_t* vis, float* depth, uint32_t* counters, int tiles_x, int tiles_y) {
-  hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, tile_offset, bin_list, vis, depth, counters);
+void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, const uint32_t* counters, int tiles_x, int tiles_y) {
+  hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters);
 }
