@@ -152,7 +152,9 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
   }
   if ((size_t)n_tiles > c->tile_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_dev(c->d_tile_count); free_dev(c->d_bins);
+    free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->d_tile_flags); free_dev(c->d_tile_list);
+    HIP_TRY(c, hipMalloc(&c->d_tile_flags, sizeof(uint32_t) * n_tiles));
+    HIP_TRY(c, hipMalloc(&c->d_tile_list, sizeof(uint32_t) * n_tiles));
     HIP_TRY(c, hipMalloc(&c->d_tile_count, sizeof(uint32_t) * n_tiles));
     HIP_TRY(c, hipMalloc(&c->d_bins, sizeof(uint32_t) * (size_t)n_tiles * PBR_BIN_CAP));
     HIP_TRY(c, hipMemset(c->d_tile_count, 0, sizeof(uint32_t) * n_tiles));   // kept clear from frame to frame by the raster kernel
@@ -210,7 +212,8 @@ static int check_sticky(PbrContext* c) {
   return PBR_OK;
 }
 
-static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, int y0, int y1, void* d_rgba8, void* d_vis, PbrFrameStats* stats) {
+static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, int y0, int y1, void* d_rgba8, void* d_vis, bool want_host_vis,
+                       PbrFrameStats* stats) {
   if (!u) return fail(c, PBR_E_ARG, "uniforms pointer is null");
   if (W <= 0 || H <= 0 || W > 16384 || H > 16384) return fail(c, PBR_E_ARG, "bad target size %dx%d", W, H);
   if (y0 < 0 || y1 > H || y0 >= y1 || (y0 & 1) || ((y1 & 1) && y1 != H)) return fail(c, PBR_E_ARG, "bad row range [%d,%d) for height %d (rows must start and end on even lines)", y0, y1, H);
@@ -257,9 +260,19 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   launch_setup_and_bin(s, dp, c->d_vout, c->d_indices, c->d_setup, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
                        (uint32_t)c->overflow_cap, c->d_counters, c->n_indices / 3, c->n_instances);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
+  // the specialised resolve covers the reference's default sampler on power-of-two textures
+  static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
+  bool fast = u->sampler_index == 15u;
+  for (int i = 0; i < 5; ++i) fast = fast && c->tex[i].srgb == kFormatSrgb[i];
+  for (int i = 0; i < 5; ++i)
+    fast = fast && (c->tex[i].w & (c->tex[i].w - 1)) == 0 && (c->tex[i].h & (c->tex[i].h - 1)) == 0 && c->tex[i].w == c->tex[0].w &&
+           c->tex[i].h == c->tex[0].h && c->tex[i].levels == c->tex[0].levels;
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
+  // the visibility entries of tiles without geometry are only written when someone will read them:
+  // the caller (vis output), the coverage count of the statistics, or the general-sampler resolve
+  const bool write_empty = d_vis != nullptr || want_host_vis || timed || !fast;
   launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
-                c->d_counters, tiles_x, tiles_y);
+                c->d_counters, c->d_tile_flags, c->d_tile_list, write_empty, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
   if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames + 1], s));
 
@@ -268,14 +281,8 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   for (int i = 0; i < 5; ++i) in.tex[i] = c->tex[i];
   in.irr = c->irr; in.pre = c->pre; in.sky = c->sky;
   in.lut = c->d_lut; in.lut_size = c->lut_size;
-  // the specialised resolve covers the reference's default sampler on power-of-two textures
-  static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
-  bool fast = u->sampler_index == 15u;
-  for (int i = 0; i < 5; ++i) fast = fast && c->tex[i].srgb == kFormatSrgb[i];
-  for (int i = 0; i < 5; ++i)
-    fast = fast && (c->tex[i].w & (c->tex[i].w - 1)) == 0 && (c->tex[i].h & (c->tex[i].h - 1)) == 0 && c->tex[i].w == c->tex[0].w &&
-           c->tex[i].h == c->tex[0].h && c->tex[i].levels == c->tex[0].levels;
-  launch_resolve(s, dp, in, pr->d_srgb_lut, vis, static_cast<uint8_t*>(d_rgba8), W, rows, fast);
+  launch_resolve(s, dp, in, pr->d_srgb_lut, vis, static_cast<uint8_t*>(d_rgba8), c->d_tile_flags, c->d_tile_list, c->d_counters, W, rows, tiles_x,
+                 tiles_y, fast);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   if (prof) { HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames + 2], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
@@ -355,7 +362,7 @@ int pbr_destroy(PbrContext* c) {
   for (auto& t : c->d_tex) free_dev(t);
   free_dev(c->d_hdr); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
-  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_tile_count); free_dev(c->d_bins);
+  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->d_tile_flags); free_dev(c->d_tile_list);
   free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
   free_dev(pr->ring.dev); free_dev(pr->d_srgb_lut);
   if (pr->ring.host) (void)hipHostFree(pr->ring.host);
@@ -659,7 +666,7 @@ int pbr_draw_frame_device(PbrContext* c, const PbrFrameUniforms* u, int32_t w, i
                           PbrFrameStats* stats) {
   if (!c) return PBR_E_ARG;
   if (!d_rgba8) return fail(c, PBR_E_ARG, "colour output pointer is null");
-  return draw_common(c, u, w, h, y0, y1, d_rgba8, d_vis, stats);
+  return draw_common(c, u, w, h, y0, y1, d_rgba8, d_vis, false, stats);
 }
 
 int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1, uint8_t* rgba8_out, uint32_t* vis_out,
@@ -672,7 +679,7 @@ int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t 
   const int rows = y1 - y0;
   int rc = ensure_frame_buffers(c, w, rows, ((w + PBR_TILE - 1) / PBR_TILE) * ((rows + PBR_TILE - 1) / PBR_TILE));
   if (rc) return rc;
-  rc = draw_common(c, u, w, h, y0, y1, c->d_color, nullptr, stats);
+  rc = draw_common(c, u, w, h, y0, y1, c->d_color, nullptr, vis_out != nullptr, stats);
   if (rc) return rc;
   const size_t npix = (size_t)w * rows;
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -101,8 +101,9 @@ struct PbrContext {
   VertexOut* d_vout = nullptr;    size_t vout_cap = 0;
   SetupTri* d_setup = nullptr;    size_t setup_cap = 0;
   uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0;   // [tiles], [tiles][PBR_BIN_CAP]
+  uint32_t* d_tile_flags = nullptr; uint32_t* d_tile_list = nullptr;                   // per tile: holds geometry; compact list of those that do
   uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
-  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, 
+  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6] tiles holding geometry
   bool capture_depth = false;
   uint32_t* h_counters = nullptr; // pinned mirror
   uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0;
@@ -132,7 +133,8 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* 
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           int n_tris, int n_instances);
 void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                   uint32_t overflow_cap, uint32_t* vis, float* depth, const uint32_t* counters, int tiles_x, int tiles_y);
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* tile_flags, uint32_t* tile_list, bool write_empty,
+                   int tiles_x, int tiles_y);
 struct ResolveInputs {
   const VertexOut* vout;
   const uint16_t* indices;
@@ -142,5 +144,5 @@ struct ResolveInputs {
   int32_t lut_size;
 };
 void launch_resolve(hipStream_t s, const FrameParams* p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    int W, int rows, bool fast);
+                    const uint32_t* tile_flags, const uint32_t* tile_list, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast);
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered);

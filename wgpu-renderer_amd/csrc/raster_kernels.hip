@@ -24,7 +24,7 @@ __global__ void __launch_bounds__(256) vertex_kernel(const FrameParams* __restri
   const int inst = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   // first kernel of a frame: re-arm the setup-triangle and bin-overflow counters the later kernels append with
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { counters[0] = 0u; counters[1] = 0u; }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { counters[0] = 0u; counters[1] = 0u; counters[6] = 0u; }
   if (i >= n_verts) return;
   float model[16], nmat[16], pvm[16];
   const float* msrc = p->has_instance_mats ? inst_model + 16 * inst : p->u.model;
@@ -239,7 +239,8 @@ PBR_DEV long long bcast64(long long v, int src_lane) {
 __global__ void __launch_bounds__(256) raster_kernel(const FrameParams* __restrict__ p, const SetupTri* __restrict__ setup,
                                                      uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
                                                      const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
-                                                     float* __restrict__ depth, const uint32_t* __restrict__ counters) {
+                                                     float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ tile_flags,
+                                                     uint32_t* __restrict__ tile_list, int write_empty) {
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
   const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -352,7 +353,13 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams* __restri
     }
     __syncthreads();
   }
-  if (tid == 0) tile_count[tile] = 0u;   // leave the bin counters clear for the next frame
+  if (tid == 0) {
+    tile_count[tile] = 0u;   // leave the bin counters clear for the next frame
+    // tell the resolve which tiles hold geometry: a flag per tile, and a compact list of the non-empty ones
+    tile_flags[tile] = n != 0u;
+    if (n != 0u) tile_list[atomicAdd(&counters[6], 1u)] = (uint32_t)tile;
+  }
+  if (n == 0u && !write_empty) return;   // nothing reads the visibility entries of an empty tile
 
   // write the tile out: thread t holds pixels 4t .. 4t+3 of the row-major tile
   const int ty = tid >> 3, tx = (tid & 7) * 4;
@@ -398,6 +405,8 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* 
 }
 
 void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                   uint32_t overflow_cap, uint32_t* vis, float* depth, const uint32_t* counters, int tiles_x, int tiles_y) {
-  hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters);
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* tile_flags, uint32_t* tile_list, bool write_empty,
+                   int tiles_x, int tiles_y) {
+  hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
+                     tile_flags, tile_list, write_empty ? 1 : 0);
 }

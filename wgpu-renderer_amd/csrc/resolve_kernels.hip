@@ -621,19 +621,16 @@ PBR_DEV void tbn_reflect(const FrameParams* p, const V3& T, const Varyings& v, V
   R = v3(r.x, r.y, -r.z);
 }
 
-__global__ void __launch_bounds__(256) resolve_surface_fast_kernel(const FrameParams* __restrict__ p, ResolveInputs in, const float* __restrict__ srgb_lut,
-                                                                   const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8) {
-  __shared__ float s_srgb[256];
+// Shades the covered pixels of the 32 x 8 pixel block whose first pixel is (blk_x * 32, y0 + blk_y * 8).
+PBR_DEV void surface_fast_block(const FrameParams* __restrict__ p, const ResolveInputs& in, const float* s_srgb, const uint32_t* __restrict__ vis,
+                                uint32_t* __restrict__ rgba8, int blk_x, int blk_y) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & 3, quad = lane >> 2;
-  const int qx = blockIdx.x * 32 + quad * 2, qy = p->y0 + blockIdx.y * 8 + wave * 2;
+  const int qx = blk_x * 32 + quad * 2, qy = p->y0 + blk_y * 8 + wave * 2;
   const int x = qx + (sub & 1), y = qy + (sub >> 1);
   const bool live = x < p->W && y < p->y1;
   const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
   const uint32_t id = live ? vis[o] : 0u;                                       // round 1
-  if (__syncthreads_or(id != 0u) == 0) return;
-  s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
-  __syncthreads();
   if (__ballot(id != 0u) == 0ull) return;
   const int qbase = lane & ~3;
   const uint32_t id0 = __shfl(id, qbase), id1 = __shfl(id, qbase + 1), id2 = __shfl(id, qbase + 2);
@@ -768,19 +765,41 @@ __global__ void __launch_bounds__(256) resolve_surface_fast_kernel(const FramePa
   if (cov) rgba8[o] = pack_color(v3(ambient.x + Lo.x + emissive.x, ambient.y + Lo.y + emissive.y, ambient.z + Lo.z + emissive.z));
 }
 
-// Background pixels: fs_main of skybox.wgsl:24-33.  One thread shades four horizontally adjacent
-// pixels: one 16-byte visibility read, sixteen independent cube taps in flight, one 16-byte store.
+// Work list driven: the rasteriser appends every tile that received a triangle to `tile_list`; each
+// workgroup strides over (tile, quarter) items, a quarter being 32 x 8 pixels.  Background-only
+// tiles — most of the frame — never start a wavefront here.
+__global__ void __launch_bounds__(256) resolve_surface_fast_kernel(const FrameParams* __restrict__ p, ResolveInputs in, const float* __restrict__ srgb_lut,
+                                                                   const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8,
+                                                                   const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ counters) {
+  __shared__ float s_srgb[256];
+  s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
+  __syncthreads();
+  const uint32_t n_items = counters[6] * (PBR_TILE / 8);
+  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint32_t tile = tile_list[item / (PBR_TILE / 8)];
+    const int tx = (int)(tile % (uint32_t)p->tiles_x), ty = (int)(tile / (uint32_t)p->tiles_x);
+    surface_fast_block(p, in, s_srgb, vis, rgba8, tx, ty * (PBR_TILE / 8) + (int)(item % (PBR_TILE / 8)));
+  }
+}
+
+// Background pixels: fs_main of skybox.wgsl:24-33.  One workgroup per raster tile (32 x 32 pixels),
+// one thread per four horizontally adjacent pixels: sixteen independent cube taps in flight and one
+// 16-byte store.  A tile the rasteriser left empty is all background, so its visibility entries are
+// not even read.
 __global__ void __launch_bounds__(256) resolve_sky_kernel(const FrameParams* __restrict__ p, DevCube sky, const uint32_t* __restrict__ vis,
-                                                          uint32_t* __restrict__ rgba8) {
-  const int x0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = p->y0 + blockIdx.y * 4 + (threadIdx.x >> 6);
+                                                          const uint32_t* __restrict__ tile_flags, uint32_t* __restrict__ rgba8) {
+  const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
+  const int x0 = blockIdx.x * PBR_TILE + (threadIdx.x & 7) * 4, y = p->y0 + blockIdx.y * PBR_TILE + (threadIdx.x >> 3);
   const int W = p->W;
   if (x0 >= W || y >= p->y1) return;
   const size_t o = (size_t)(y - p->y0) * W + x0;
   const bool wide = x0 + 3 < W && (o & 3) == 0;
-  uint32_t id[4] = {1u, 1u, 1u, 1u};
-  if (wide) { const uint4 v = *reinterpret_cast<const uint4*>(vis + o); id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w; }
-  else { for (int k = 0; k < 4; ++k) if (x0 + k < W) id[k] = vis[o + k]; }
-  if (id[0] && id[1] && id[2] && id[3]) return;
+  uint32_t id[4] = {0u, 0u, 0u, 0u};
+  if (tile_flags[tile] != 0u) {
+    if (wide) { const uint4 v = *reinterpret_cast<const uint4*>(vis + o); id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w; }
+    else { for (int k = 0; k < 4; ++k) if (x0 + k < W) id[k] = vis[o + k]; }
+    if (id[0] && id[1] && id[2] && id[3]) return;
+  }
   const float* m = p->u.inv_view_proj;
   const float yn = 1.0f - ((float)y + 0.5f) / (float)p->H * 2.0f;
   CubeFoot foot[4];
@@ -826,14 +845,16 @@ __global__ void __launch_bounds__(256) count_covered_kernel(const uint32_t* __re
 }  // namespace
 
 void launch_resolve(hipStream_t s, const FrameParams* p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    int W, int rows, bool fast) {
+                    const uint32_t* tile_flags, const uint32_t* tile_list, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast) {
   uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
-  hipLaunchKernelGGL(resolve_sky_kernel, dim3((W + 255) / 256, (rows + 3) / 4), dim3(256), 0, s, p, in.sky, vis, out);
-  dim3 grid((W + 31) / 32, (rows + 7) / 8);
-  if (fast)
-    hipLaunchKernelGGL(resolve_surface_fast_kernel, grid, dim3(256), 0, s, p, in, srgb_lut, vis, out);
-  else
+  hipLaunchKernelGGL(resolve_sky_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, in.sky, vis, tile_flags, out);
+  if (fast) {
+    const int blocks = std::min(tiles_x * tiles_y * (PBR_TILE / 8), 3072);
+    hipLaunchKernelGGL(resolve_surface_fast_kernel, dim3(blocks), dim3(256), 0, s, p, in, srgb_lut, vis, out, tile_list, counters);
+  } else {
+    dim3 grid((W + 31) / 32, (rows + 7) / 8);
     hipLaunchKernelGGL(resolve_surface_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis, out);
+  }
 }
 
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered) {
