@@ -143,10 +143,13 @@ int pbr_debug_vertex_stage(PbrContext* ctx, const PbrFrameUniforms* u, float* cl
 int pbr_debug_capture_depth(PbrContext* ctx, int32_t enable);
 int pbr_debug_depth(PbrContext* ctx, float* depth_out, size_t n_floats);
 
-/* ---- kernel timing for benchmarks: HIP events recorded on the context's stream around the
- * resolve kernel of every frame drawn while enabled. ---- */
+/* ---- kernel timing for benchmarks: HIP events recorded on the context's stream inside every frame
+ * drawn while enabled.  pbr_profile_end waits for the stream and returns the number of frames and four
+ * sums in milliseconds: [0] vertex + setup + raster kernels, [1] sky resolve kernel, [2] surface
+ * resolve kernel, [3] first launch to last completion.  No counterpart in the reference beyond its
+ * timestamp query (renderer.ts:1968-1974). ---- */
 int pbr_profile_begin(PbrContext* ctx, int32_t max_frames);
-int pbr_profile_end(PbrContext* ctx, int32_t* frames, float* resolve_ms_total, float* raster_ms_total, float* frame_ms_total);
+int pbr_profile_end(PbrContext* ctx, int32_t* frames, float* ms_totals /* [4] */);
 
 #ifdef __cplusplus
 }

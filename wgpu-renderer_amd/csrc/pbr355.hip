@@ -253,7 +253,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   const bool timed = stats != nullptr;
   const bool prof = c->profiling && c->prof_frames < c->prof_cap;
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], s));
-  if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames], s));
+  if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[4 * c->prof_frames], s));
 
   launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
@@ -274,7 +274,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
                 c->d_counters, c->d_tile_flags, c->d_tile_list, write_empty, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
-  if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames + 1], s));
+  if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[4 * c->prof_frames + 1], s));
 
   ResolveInputs in;
   in.vout = c->d_vout; in.indices = c->d_indices;
@@ -282,9 +282,9 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   in.irr = c->irr; in.pre = c->pre; in.sky = c->sky;
   in.lut = c->d_lut; in.lut_size = c->lut_size;
   launch_resolve(s, dp, in, pr->d_srgb_lut, vis, static_cast<uint8_t*>(d_rgba8), c->d_tile_flags, c->d_tile_list, c->d_counters, W, rows, tiles_x,
-                 tiles_y, fast);
+                 tiles_y, fast, prof ? c->prof_events[4 * c->prof_frames + 2] : nullptr);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
-  if (prof) { HIP_TRY(c, hipEventRecord(c->prof_events[3 * c->prof_frames + 2], s)); ++c->prof_frames; }
+  if (prof) { HIP_TRY(c, hipEventRecord(c->prof_events[4 * c->prof_frames + 3], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
   c->last_w = W; c->last_rows = rows;
   ++pr->frames_drawn;
@@ -737,7 +737,7 @@ int pbr_debug_depth(PbrContext* c, float* depth_out, size_t n_floats) {
 int pbr_profile_begin(PbrContext* c, int32_t max_frames) {
   if (!c || max_frames <= 0 || max_frames > (1 << 20)) return c ? fail(c, PBR_E_ARG, "bad frame count") : PBR_E_ARG;
   DeviceGuard guard(c->device);
-  while ((int)c->prof_events.size() < 3 * max_frames) {
+  while ((int)c->prof_events.size() < 4 * max_frames) {
     hipEvent_t ev;
     HIP_TRY(c, hipEventCreate(&ev));
     c->prof_events.push_back(ev);
@@ -746,21 +746,21 @@ int pbr_profile_begin(PbrContext* c, int32_t max_frames) {
   return PBR_OK;
 }
 
-int pbr_profile_end(PbrContext* c, int32_t* frames, float* resolve_ms_total, float* raster_ms_total, float* frame_ms_total) {
+int pbr_profile_end(PbrContext* c, int32_t* frames, float* ms_totals) {
   if (!c) return PBR_E_ARG;
   DeviceGuard guard(c->device);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  float resolve = 0, geom = 0, total = 0;
+  float sum[4] = {0, 0, 0, 0};   // geometry (vertex + setup + raster), sky resolve, surface resolve, whole frame
   for (int i = 0; i < c->prof_frames; ++i) {
-    float a = 0, b = 0;
-    HIP_TRY(c, hipEventElapsedTime(&a, c->prof_events[3 * i], c->prof_events[3 * i + 1]));
-    HIP_TRY(c, hipEventElapsedTime(&b, c->prof_events[3 * i + 1], c->prof_events[3 * i + 2]));
-    geom += a; resolve += b; total += a + b;
+    hipEvent_t* e = &c->prof_events[4 * i];
+    float part[3];
+    for (int k = 0; k < 3; ++k) HIP_TRY(c, hipEventElapsedTime(&part[k], e[k], e[k + 1]));
+    float whole = 0;
+    HIP_TRY(c, hipEventElapsedTime(&whole, e[0], e[3]));
+    sum[0] += part[0]; sum[1] += part[1]; sum[2] += part[2]; sum[3] += whole;
   }
   if (frames) *frames = c->prof_frames;
-  if (resolve_ms_total) *resolve_ms_total = resolve;
-  if (raster_ms_total) *raster_ms_total = geom;
-  if (frame_ms_total) *frame_ms_total = total;
+  if (ms_totals) for (int k = 0; k < 4; ++k) ms_totals[k] = sum[k];
   c->profiling = false;
   return PBR_OK;
 }

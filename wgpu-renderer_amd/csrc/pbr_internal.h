@@ -144,5 +144,5 @@ struct ResolveInputs {
   int32_t lut_size;
 };
 void launch_resolve(hipStream_t s, const FrameParams* p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    const uint32_t* tile_flags, const uint32_t* tile_list, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast);
+                    const uint32_t* tile_flags, const uint32_t* tile_list, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, hipEvent_t between);
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered);

@@ -845,9 +845,11 @@ __global__ void __launch_bounds__(256) count_covered_kernel(const uint32_t* __re
 }  // namespace
 
 void launch_resolve(hipStream_t s, const FrameParams* p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    const uint32_t* tile_flags, const uint32_t* tile_list, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast) {
+                    const uint32_t* tile_flags, const uint32_t* tile_list, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast,
+                    hipEvent_t between) {
   uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
   hipLaunchKernelGGL(resolve_sky_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, in.sky, vis, tile_flags, out);
+  if (between) (void)hipEventRecord(between, s);   // separates the two kernels for per-kernel timing
   if (fast) {
     const int blocks = std::min(tiles_x * tiles_y * (PBR_TILE / 8), 3072);
     hipLaunchKernelGGL(resolve_surface_fast_kernel, dim3(blocks), dim3(256), 0, s, p, in, srgb_lut, vis, out, tile_list, counters);
