@@ -72,14 +72,29 @@ def look_at(eye, target, up):
 
 
 def mul(a, b):
-    a = np.asarray(a, dtype=np.float64).reshape(4, 4)   # row c of the reshape is column c of the matrix
-    b = np.asarray(b, dtype=np.float64).reshape(4, 4)
-    return (b @ a).astype(np.float32).reshape(16)
+    """mat4.mul: a . b, each element summed left to right in f64."""
+    a = [float(x) for x in a]
+    b = [float(x) for x in b]
+    out = [0.0] * 16
+    for c in range(4):
+        for r in range(4):
+            out[4 * c + r] = a[r] * b[4 * c] + a[4 + r] * b[4 * c + 1] + a[8 + r] * b[4 * c + 2] + a[12 + r] * b[4 * c + 3]
+    return _f32(out)
 
 
 def inverse(m):
-    a = np.asarray(m, dtype=np.float64).reshape(4, 4)
-    return np.linalg.inv(a).astype(np.float32).reshape(16)
+    """mat4.inverse by Laplace expansion over the 2x2 minors of the top and bottom row pairs (f64)."""
+    (a00, a10, a20, a30, a01, a11, a21, a31, a02, a12, a22, a32, a03, a13, a23, a33) = (float(x) for x in m)
+    s0 = a00 * a11 - a10 * a01; s1 = a00 * a12 - a10 * a02; s2 = a00 * a13 - a10 * a03
+    s3 = a01 * a12 - a11 * a02; s4 = a01 * a13 - a11 * a03; s5 = a02 * a13 - a12 * a03
+    c5 = a22 * a33 - a32 * a23; c4 = a21 * a33 - a31 * a23; c3 = a21 * a32 - a31 * a22
+    c2 = a20 * a33 - a30 * a23; c1 = a20 * a32 - a30 * a22; c0 = a20 * a31 - a30 * a21
+    d = 1 / (s0 * c5 - s1 * c4 + s2 * c3 + s3 * c2 - s4 * c1 + s5 * c0)
+    return _f32([
+        (a11 * c5 - a12 * c4 + a13 * c3) * d, (-a10 * c5 + a12 * c2 - a13 * c1) * d, (a10 * c4 - a11 * c2 + a13 * c0) * d, (-a10 * c3 + a11 * c1 - a12 * c0) * d,
+        (-a01 * c5 + a02 * c4 - a03 * c3) * d, (a00 * c5 - a02 * c2 + a03 * c1) * d, (-a00 * c4 + a01 * c2 - a03 * c0) * d, (a00 * c3 - a01 * c1 + a02 * c0) * d,
+        (a31 * s5 - a32 * s4 + a33 * s3) * d, (-a30 * s5 + a32 * s2 - a33 * s1) * d, (a30 * s4 - a31 * s2 + a33 * s0) * d, (-a30 * s3 + a31 * s1 - a32 * s0) * d,
+        (-a21 * s5 + a22 * s4 - a23 * s3) * d, (a20 * s5 - a22 * s2 + a23 * s1) * d, (-a20 * s4 + a21 * s2 - a23 * s0) * d, (a20 * s3 - a21 * s1 + a22 * s0) * d])
 
 
 def transpose(m):
