@@ -143,13 +143,14 @@ int pbr_debug_vertex_stage(PbrContext* ctx, const PbrFrameUniforms* u, float* cl
 int pbr_debug_capture_depth(PbrContext* ctx, int32_t enable);
 int pbr_debug_depth(PbrContext* ctx, float* depth_out, size_t n_floats);
 
-/* ---- kernel timing for benchmarks: HIP events recorded on the context's stream inside every frame
- * drawn while enabled.  pbr_profile_end waits for the stream and returns the number of frames and four
- * sums in milliseconds: [0] vertex + setup + raster kernels, [1] sky resolve kernel, [2] surface
- * resolve kernel, [3] first launch to last completion.  No counterpart in the reference beyond its
- * timestamp query (renderer.ts:1968-1974). ---- */
+/* ---- kernel timing for benchmarks: while enabled, every frame records one HIP event before and one
+ * after its surface-shading kernel (the frame's dominant kernel) on the context's stream.
+ * pbr_profile_end waits for the stream and returns the number of frames, the summed duration of that
+ * kernel in milliseconds, and span_ms = the time from the end of the first profiled frame to the end
+ * of the last (so span_ms / (frames - 1) is the device time per frame, gaps included).  No counterpart
+ * in the reference beyond its timestamp query (renderer.ts:1968-1974). ---- */
 int pbr_profile_begin(PbrContext* ctx, int32_t max_frames);
-int pbr_profile_end(PbrContext* ctx, int32_t* frames, float* ms_totals /* [4] */);
+int pbr_profile_end(PbrContext* ctx, int32_t* frames, float* surface_ms_total, float* span_ms);
 
 #ifdef __cplusplus
 }

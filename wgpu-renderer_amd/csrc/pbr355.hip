@@ -152,9 +152,8 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
   }
   if ((size_t)n_tiles > c->tile_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->d_tile_flags); free_dev(c->d_tile_list);
-    HIP_TRY(c, hipMalloc(&c->d_tile_flags, sizeof(uint32_t) * n_tiles));
-    HIP_TRY(c, hipMalloc(&c->d_tile_list, sizeof(uint32_t) * n_tiles));
+    free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->d_row_pairs);
+    HIP_TRY(c, hipMalloc(&c->d_row_pairs, sizeof(uint32_t) * (size_t)n_tiles * (PBR_TILE / 2)));
     HIP_TRY(c, hipMalloc(&c->d_tile_count, sizeof(uint32_t) * n_tiles));
     HIP_TRY(c, hipMalloc(&c->d_bins, sizeof(uint32_t) * (size_t)n_tiles * PBR_BIN_CAP));
     HIP_TRY(c, hipMemset(c->d_tile_count, 0, sizeof(uint32_t) * n_tiles));   // kept clear from frame to frame by the raster kernel
@@ -173,26 +172,21 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
   return PBR_OK;
 }
 
-constexpr int PARAM_SLOTS = 16;
-struct ParamRing {
-  FrameParams* host = nullptr;   // pinned
-  FrameParams* dev = nullptr;
-  hipEvent_t done[PARAM_SLOTS] = {};
-  bool used[PARAM_SLOTS] = {};
-  int next = 0;
-};
-
 }  // namespace
 
-// The ring lives behind the context; keeping it out of the header keeps PbrContext plain.
+// State that lives behind the context; keeping it out of the header keeps PbrContext plain.
 struct PbrContextPrivate {
-  ParamRing ring;
   float* d_srgb_lut = nullptr;
   int prefilter_tables_for = -1;          // mips the cached sample tables were built for
   int prefilter_src_levels = -1;
   int table_count[PBR_MAX_LEVELS] = {};
   float table_weight[PBR_MAX_LEVELS] = {};
   uint32_t frames_drawn = 0;
+  // Bordered copies of the cube maps for the resolve: every face carries the adjoining texels of its
+  // neighbours (and the three-texel mean at corners), so a bilinear lookup never leaves its face.
+  struct Bordered { float4* d = nullptr; DevCube cube = {}; bool dirty = true; };
+  Bordered sky_b, irr_b, pre_b;
+  int surface_blocks = 0;                 // resident workgroups of the surface kernel on this device
 };
 static PbrContextPrivate* priv_of(PbrContext* c);
 
@@ -209,6 +203,26 @@ static int check_sticky(PbrContext* c) {
     (void)hipMemset(&c->d_counters[2], 0, sizeof(uint32_t));
     return fail(c, PBR_E_STATE, code == 1 ? "triangle setup buffer overflow" : "tile bin overflow list full");
   }
+  return PBR_OK;
+}
+
+static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const DevCube& src) {
+  if (!b.dirty && b.d) return PBR_OK;
+  if (!b.d || b.cube.size != src.size || b.cube.levels != src.levels) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (b.d) { (void)hipFree(b.d); b.d = nullptr; }
+    size_t total = 0;
+    for (int l = 0; l < src.levels; ++l) {
+      const size_t n = (size_t)std::max(1, src.size >> l);
+      b.cube.off[l] = (uint32_t)total;
+      total += 6 * (n + 2) * (n + 2);
+    }
+    if (total > 0xffffffffull) return fail(c, PBR_E_ARG, "cube map too large");
+    HIP_TRY(c, hipMalloc(&b.d, total * sizeof(float4)));
+    b.cube.base = b.d; b.cube.size = src.size; b.cube.levels = src.levels;
+  }
+  for (int l = 0; l < src.levels; ++l) launch_cube_border(c->stream, src, l, b.d + b.cube.off[l]);
+  b.dirty = false;
   return PBR_OK;
 }
 
@@ -233,27 +247,23 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   int rc = ensure_frame_buffers(c, W, rows, tiles_x * tiles_y);
   if (rc) return rc;
 
-  // stage the per-frame parameters
-  ParamRing& ring = pr->ring;
-  const int slot = ring.next;
-  ring.next = (ring.next + 1) % PARAM_SLOTS;
-  if (ring.used[slot]) HIP_TRY(c, hipEventSynchronize(ring.done[slot]));
-  FrameParams& fp = ring.host[slot];
+  // per-frame parameters travel as kernel arguments
+  FrameParams fp;
   fp.u = *u;
   mat4_mul_host(u->projection, u->view, fp.pv);
   fp.W = W; fp.H = H; fp.y0 = y0; fp.y1 = y1; fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances;
   fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
-  FrameParams* dp = ring.dev + slot;
+  const FrameParams& dp = fp;
   hipStream_t s = c->stream;
-  HIP_TRY(c, hipMemcpyAsync(dp, &fp, sizeof(FrameParams), hipMemcpyHostToDevice, s));
-  HIP_TRY(c, hipEventRecord(ring.done[slot], s));
-  ring.used[slot] = true;
+
+  if ((rc = refresh_bordered(c, pr->sky_b, c->sky)) || (rc = refresh_bordered(c, pr->irr_b, c->irr)) || (rc = refresh_bordered(c, pr->pre_b, c->pre))) return rc;
 
   const bool timed = stats != nullptr;
   const bool prof = c->profiling && c->prof_frames < c->prof_cap;
+  hipEvent_t* pe = prof ? &c->prof_events[2 * c->prof_frames] : nullptr;   // surface pass begin, end
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], s));
-  if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[4 * c->prof_frames], s));
+  uint8_t* color = static_cast<uint8_t*>(d_rgba8);
 
   launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
@@ -272,19 +282,19 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // the caller (vis output), the coverage count of the statistics, or the general-sampler resolve
   const bool write_empty = d_vis != nullptr || want_host_vis || timed || !fast;
   launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
-                c->d_counters, c->d_tile_flags, c->d_tile_list, write_empty, tiles_x, tiles_y);
+                c->d_counters, c->d_row_pairs, write_empty, pr->sky_b.cube, color, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
-  if (prof) HIP_TRY(c, hipEventRecord(c->prof_events[4 * c->prof_frames + 1], s));
 
   ResolveInputs in;
   in.vout = c->d_vout; in.indices = c->d_indices;
   for (int i = 0; i < 5; ++i) in.tex[i] = c->tex[i];
   in.irr = c->irr; in.pre = c->pre; in.sky = c->sky;
+  in.irr_b = pr->irr_b.cube; in.pre_b = pr->pre_b.cube; in.sky_b = pr->sky_b.cube;
   in.lut = c->d_lut; in.lut_size = c->lut_size;
-  launch_resolve(s, dp, in, pr->d_srgb_lut, vis, static_cast<uint8_t*>(d_rgba8), c->d_tile_flags, c->d_tile_list, c->d_counters, W, rows, tiles_x,
-                 tiles_y, fast, prof ? c->prof_events[4 * c->prof_frames + 2] : nullptr);
+  if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
+  launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->d_row_pairs, c->d_counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
-  if (prof) { HIP_TRY(c, hipEventRecord(c->prof_events[4 * c->prof_frames + 3], s)); ++c->prof_frames; }
+  if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
   c->last_w = W; c->last_rows = rows;
   ++pr->frames_drawn;
@@ -332,15 +342,17 @@ int pbr_create(int device_ordinal, PbrContext** ctx_out) {
   };
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   c->stream = c->own_stream;
+  {
+    PbrContextPrivate* pr = &box->priv;
+    hipDeviceProp_t dp;
+    if ((e = hipGetDeviceProperties(&dp, device_ordinal)) != hipSuccess) return bail("hipGetDeviceProperties", e);
+    pr->surface_blocks = dp.multiProcessorCount * surface_fast_blocks_per_cu();
+  }
   for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&c->d_counters, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
   if ((e = hipHostMalloc(&c->h_counters, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
   std::memset(c->h_counters, 0, 8 * sizeof(uint32_t));
-  ParamRing& ring = box->priv.ring;
-  if ((e = hipHostMalloc(&ring.host, PARAM_SLOTS * sizeof(FrameParams))) != hipSuccess) return bail("hipHostMalloc", e);
-  if ((e = hipMalloc(&ring.dev, PARAM_SLOTS * sizeof(FrameParams))) != hipSuccess) return bail("hipMalloc", e);
-  for (auto& ev : ring.done) if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) return bail("hipEventCreate", e);
   if ((e = hipMalloc(&c->d_samples, sizeof(PrefilterSample) * PBR_PREFILTER_SAMPLES * PBR_MAX_LEVELS)) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&c->d_irr_tables, sizeof(float) * 2 * (512 + 128))) != hipSuccess) return bail("hipMalloc", e);
   {
@@ -361,13 +373,12 @@ int pbr_destroy(PbrContext* c) {
   free_dev(c->d_vsoa); free_dev(c->d_indices); free_dev(c->d_inst_model); free_dev(c->d_inst_normal);
   for (auto& t : c->d_tex) free_dev(t);
   free_dev(c->d_hdr); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
+  { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); }
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
-  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->d_tile_flags); free_dev(c->d_tile_list);
+  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->d_row_pairs);
   free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
-  free_dev(pr->ring.dev); free_dev(pr->d_srgb_lut);
-  if (pr->ring.host) (void)hipHostFree(pr->ring.host);
+  free_dev(pr->d_srgb_lut);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
-  for (auto& ev : pr->ring.done) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->prof_events) if (ev) (void)hipEventDestroy(ev);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -486,6 +497,7 @@ int pbr_ibl_equirect_to_cube(PbrContext* c, int32_t size) {
     c->sky.base = c->d_sky; c->sky.size = size; c->sky.levels = 1;
   }
   launch_equirect_to_cube(c->stream, c->hdr, c->d_sky, size);
+  priv_of(c)->sky_b.dirty = true;
   HIP_TRY(c, hipGetLastError());
   return PBR_OK;
 }
@@ -515,6 +527,7 @@ int pbr_ibl_irradiance(PbrContext* c, int32_t size) {
   tables.insert(tables.end(), st.begin(), st.end()); tables.insert(tables.end(), ct.begin(), ct.end());
   HIP_TRY(c, hipMemcpy(c->d_irr_tables, tables.data(), tables.size() * sizeof(float), hipMemcpyHostToDevice));
   launch_irradiance(c->stream, c->hdr, c->d_irr_tables, n_phi, n_theta, c->d_irr, size);
+  priv_of(c)->irr_b.dirty = true;
   HIP_TRY(c, hipGetLastError());
   return PBR_OK;
 }
@@ -573,6 +586,7 @@ int pbr_ibl_prefilter(PbrContext* c, int32_t size, int32_t mips, int32_t samples
     launch_prefilter(c->stream, c->hdr, c->d_samples + (size_t)m * PBR_PREFILTER_SAMPLES, pr->table_count[m], pr->table_weight[m],
                      c->d_pre + lo, (int)s, (int64_t)(a - lo), (int64_t)(b - a));
   }
+  pr->pre_b.dirty = true;
   HIP_TRY(c, hipGetLastError());
   return PBR_OK;
 }
@@ -657,6 +671,11 @@ int pbr_ibl_device_ptr(PbrContext* c, int which, void** dev_ptr, size_t* total_b
     default: return fail(c, PBR_E_ARG, "unknown map %d", which);
   }
   if (!p) return fail(c, PBR_E_STATE, "map %d not generated", which);
+  // the caller may write through this pointer (e.g. an all-gather of shards): derived copies are rebuilt at the next frame
+  PbrContextPrivate* pr = priv_of(c);
+  if (which == PBR_MAP_SKYBOX) pr->sky_b.dirty = true;
+  if (which == PBR_MAP_IRRADIANCE) pr->irr_b.dirty = true;
+  if (which == PBR_MAP_PREFILTER) pr->pre_b.dirty = true;
   *dev_ptr = p;
   if (total_bytes) *total_bytes = bytes;
   return PBR_OK;
@@ -695,15 +714,13 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   DeviceGuard guard(c->device);
   int rc = ensure_frame_buffers(c, 32, 32, 1);
   if (rc) return rc;
-  PbrContextPrivate* pr = priv_of(c);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  FrameParams& fp = pr->ring.host[0];
+  FrameParams fp;
   fp.u = *u;
   mat4_mul_host(u->projection, u->view, fp.pv);
   fp.W = 32; fp.H = 32; fp.y0 = 0; fp.y1 = 32; fp.tiles_x = 1; fp.tiles_y = 1;
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances; fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
-  HIP_TRY(c, hipMemcpy(pr->ring.dev, &fp, sizeof fp, hipMemcpyHostToDevice));
-  launch_vertex_stage(c->stream, pr->ring.dev, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances);
+  launch_vertex_stage(c->stream, fp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const size_t nv = (size_t)c->n_verts * c->n_instances;
   std::vector<VertexOut> host(nv);
@@ -737,7 +754,7 @@ int pbr_debug_depth(PbrContext* c, float* depth_out, size_t n_floats) {
 int pbr_profile_begin(PbrContext* c, int32_t max_frames) {
   if (!c || max_frames <= 0 || max_frames > (1 << 20)) return c ? fail(c, PBR_E_ARG, "bad frame count") : PBR_E_ARG;
   DeviceGuard guard(c->device);
-  while ((int)c->prof_events.size() < 4 * max_frames) {
+  while ((int)c->prof_events.size() < 2 * max_frames) {
     hipEvent_t ev;
     HIP_TRY(c, hipEventCreate(&ev));
     c->prof_events.push_back(ev);
@@ -746,21 +763,20 @@ int pbr_profile_begin(PbrContext* c, int32_t max_frames) {
   return PBR_OK;
 }
 
-int pbr_profile_end(PbrContext* c, int32_t* frames, float* ms_totals) {
+int pbr_profile_end(PbrContext* c, int32_t* frames, float* surface_ms_total, float* span_ms) {
   if (!c) return PBR_E_ARG;
   DeviceGuard guard(c->device);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  float sum[4] = {0, 0, 0, 0};   // geometry (vertex + setup + raster), sky resolve, surface resolve, whole frame
+  float surface = 0, span = 0;
   for (int i = 0; i < c->prof_frames; ++i) {
-    hipEvent_t* e = &c->prof_events[4 * i];
-    float part[3];
-    for (int k = 0; k < 3; ++k) HIP_TRY(c, hipEventElapsedTime(&part[k], e[k], e[k + 1]));
-    float whole = 0;
-    HIP_TRY(c, hipEventElapsedTime(&whole, e[0], e[3]));
-    sum[0] += part[0]; sum[1] += part[1]; sum[2] += part[2]; sum[3] += whole;
+    float ms = 0;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+    surface += ms;
   }
+  if (c->prof_frames > 1) HIP_TRY(c, hipEventElapsedTime(&span, c->prof_events[1], c->prof_events[2 * c->prof_frames - 1]));
   if (frames) *frames = c->prof_frames;
-  if (ms_totals) for (int k = 0; k < 4; ++k) ms_totals[k] = sum[k];
+  if (surface_ms_total) *surface_ms_total = surface;
+  if (span_ms) *span_ms = span;
   c->profiling = false;
   return PBR_OK;
 }

@@ -101,9 +101,9 @@ struct PbrContext {
   VertexOut* d_vout = nullptr;    size_t vout_cap = 0;
   SetupTri* d_setup = nullptr;    size_t setup_cap = 0;
   uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0;   // [tiles], [tiles][PBR_BIN_CAP]
-  uint32_t* d_tile_flags = nullptr; uint32_t* d_tile_list = nullptr;                   // per tile: holds geometry; compact list of those that do
+  uint32_t* d_row_pairs = nullptr;                                                     // work list of the resolve: tile * 16 + row pair, [tiles * 16]
   uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
-  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6] tiles holding geometry
+  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6] row pairs holding geometry
   bool capture_depth = false;
   uint32_t* h_counters = nullptr; // pinned mirror
   uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0;
@@ -127,22 +127,26 @@ void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* sam
                       float4* out_level, int level_size, int64_t first, int64_t count);
 void launch_brdf_lut(hipStream_t s, uint16_t* out, int size);
 
-void launch_vertex_stage(hipStream_t s, const FrameParams* p, const float* vsoa, const float* inst_model, const float* inst_normal,
+void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa, const float* inst_model, const float* inst_normal,
                          VertexOut* out, uint32_t* counters, int n_verts, int n_instances);
-void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
+void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           int n_tris, int n_instances);
-void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* tile_flags, uint32_t* tile_list, bool write_empty,
-                   int tiles_x, int tiles_y);
+void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* row_pairs, bool write_empty,
+                   const DevCube& sky_bordered, uint8_t* rgba8, int tiles_x, int tiles_y);
 struct ResolveInputs {
   const VertexOut* vout;
   const uint16_t* indices;
   DevTex8 tex[5];
   DevCube irr, pre, sky;
+  DevCube irr_b, pre_b, sky_b;   // the same maps with a one-texel border per face (level l: [6][n+2][n+2], n = size >> l)
   const uint16_t* lut;
   int32_t lut_size;
 };
-void launch_resolve(hipStream_t s, const FrameParams* p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    const uint32_t* tile_flags, const uint32_t* tile_list, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, hipEvent_t between);
+// covered pixels; the rasteriser has already written the skybox colour of the background pixels
+void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
+                    const uint32_t* row_pairs, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks);
+int surface_fast_blocks_per_cu();
+void launch_cube_border(hipStream_t s, DevCube src, int level, float4* dst_level);
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered);

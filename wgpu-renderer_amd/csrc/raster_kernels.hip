@@ -11,6 +11,7 @@
 // explicitly rounded operations (no FMA contraction).
 #include "pbr_internal.h"
 #include "devmath.h"
+#include "sky_shade.h"
 
 namespace {
 
@@ -18,9 +19,10 @@ namespace {
 // Vertex stage.  Attribute streams are SoA (px[], py[], pz[], u[], v[], nx[], ny[], nz[]) so a
 // wavefront's 64 loads of one attribute are one contiguous 256-byte request.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) vertex_kernel(const FrameParams* __restrict__ p, const float* __restrict__ vsoa,
+__global__ void __launch_bounds__(256) vertex_kernel(const FrameParams frame_params, const float* __restrict__ vsoa,
                                                      const float* __restrict__ inst_model, const float* __restrict__ inst_normal,
                                                      VertexOut* __restrict__ out, uint32_t* __restrict__ counters, int n_verts) {
+  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   const int inst = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   // first kernel of a frame: re-arm the setup-triangle and bin-overflow counters the later kernels append with
@@ -193,8 +195,9 @@ PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint16
   for (int k = 1; k + 1 < n; ++k) emit_triangle(id, poly[0], poly[k], poly[k + 1], p, bt, nullptr);
 }
 
-__global__ void __launch_bounds__(256) setup_kernel(const FrameParams* __restrict__ p, const VertexOut* __restrict__ vout,
+__global__ void __launch_bounds__(256) setup_kernel(const FrameParams frame_params, const VertexOut* __restrict__ vout,
                                                     const uint16_t* __restrict__ indices, BinTargets bt, int n_tris) {
+  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   const int inst = blockIdx.y;
   const int t = blockIdx.x * 256 + threadIdx.x;
   Deferred d;
@@ -236,12 +239,14 @@ PBR_DEV long long bcast64(long long v, int src_lane) {
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-__global__ void __launch_bounds__(256) raster_kernel(const FrameParams* __restrict__ p, const SetupTri* __restrict__ setup,
+__global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_params, const SetupTri* __restrict__ setup,
                                                      uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
                                                      const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
-                                                     float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ tile_flags,
-                                                     uint32_t* __restrict__ tile_list, int write_empty) {
+                                                     float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ row_pairs,
+                                                     int write_empty, DevCube sky, uint32_t* __restrict__ rgba8) {
+  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
+  __shared__ uint32_t s_pairs[4];
   const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px0 = blockIdx.x * PBR_TILE, py0 = p->y0 + blockIdx.y * PBR_TILE;   // tile origin in pixels
@@ -353,46 +358,83 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams* __restri
     }
     __syncthreads();
   }
-  if (tid == 0) {
-    tile_count[tile] = 0u;   // leave the bin counters clear for the next frame
-    // tell the resolve which tiles hold geometry: a flag per tile, and a compact list of the non-empty ones
-    tile_flags[tile] = n != 0u;
-    if (n != 0u) tile_list[atomicAdd(&counters[6], 1u)] = (uint32_t)tile;
-  }
-  if (n == 0u && !write_empty) return;   // nothing reads the visibility entries of an empty tile
+  if (tid == 0) tile_count[tile] = 0u;   // leave the bin counters clear for the next frame
 
   // write the tile out: thread t holds pixels 4t .. 4t+3 of the row-major tile
   const int ty = tid >> 3, tx = (tid & 7) * 4;
   const int y = py0 + ty, x = px0 + tx;
-  if (y > ymax || x > xmax) return;
+  const bool inside = y <= ymax && x <= xmax;
   uint32_t ids[4] = {0u, 0u, 0u, 0u};
   float zs[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-  if (n != 0u) {
+  if (n != 0u && inside) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const unsigned long long key = s_key[ty * PBR_TILE + tx + k];
-      ids[k] = (uint32_t)key; zs[k] = key_depth((uint32_t)(key >> 32));
+      ids[k] = (x + k <= xmax) ? (uint32_t)key : 0u;
+      zs[k] = key_depth((uint32_t)(key >> 32));
     }
   }
-  const size_t o = (size_t)(y - p->y0) * p->W + x;
-  if (x + 3 <= xmax && (o & 3) == 0) {
-    *reinterpret_cast<uint4*>(vis + o) = make_uint4(ids[0], ids[1], ids[2], ids[3]);
-    if (depth) *reinterpret_cast<float4*>(depth + o) = make_float4(zs[0], zs[1], zs[2], zs[3]);
-  } else {
-    for (int k = 0; k < 4; ++k)
-      if (x + k <= xmax) { vis[o + k] = ids[k]; if (depth) depth[o + k] = zs[k]; }
+  if (inside) {
+    const size_t o = (size_t)(y - p->y0) * p->W + x;
+    const bool wide = x + 3 <= xmax && (o & 3) == 0;
+    // the visibility entries of a tile without geometry are only written when someone will read them
+    if (n != 0u || write_empty) {
+      if (wide) {
+        *reinterpret_cast<uint4*>(vis + o) = make_uint4(ids[0], ids[1], ids[2], ids[3]);
+        if (depth) *reinterpret_cast<float4*>(depth + o) = make_float4(zs[0], zs[1], zs[2], zs[3]);
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (x + k <= xmax) { vis[o + k] = ids[k]; if (depth) depth[o + k] = zs[k]; }
+      }
+    }
+    // The background pixels of the tile get their final colour here (skybox.wgsl:24-33): most tiles hold no
+    // geometry at all, and their workgroups would otherwise have nothing to do.
+    if (!(ids[0] && ids[1] && ids[2] && ids[3])) {
+      uint32_t c[4];
+      sky_pixels4(p, sky, x, y, c);
+      if (wide && !(ids[0] | ids[1] | ids[2] | ids[3])) {
+        *reinterpret_cast<uint4*>(rgba8 + o) = make_uint4(c[0], c[1], c[2], c[3]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (x + k <= xmax && !ids[k]) rgba8[o + k] = c[k];
+      }
+    }
+  }
+  if (n == 0u) return;
+
+  // Work list for the shading resolve: one item per pair of pixel rows of this tile (32 x 2 pixels, the
+  // footprint of one resolve wavefront) that holds at least one covered pixel.  A wave here owns eight
+  // rows, sixteen lanes per row pair; one append per tile.
+  const unsigned long long covered = __ballot((ids[0] | ids[1] | ids[2] | ids[3]) != 0u);
+  if (lane == 0) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if ((covered >> (16 * k)) & 0xffffull) m |= 1u << k;
+    s_pairs[wave] = m;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t mask = s_pairs[0] | (s_pairs[1] << 4) | (s_pairs[2] << 8) | (s_pairs[3] << 12);
+    if (mask) {
+      uint32_t at = atomicAdd(&counters[6], (uint32_t)__popc(mask));
+      while (mask) {
+        const int pair = __ffs((int)mask) - 1;
+        mask &= mask - 1;
+        row_pairs[at++] = (uint32_t)tile * 16u + (uint32_t)pair;
+      }
+    }
   }
 }
 
 }  // namespace
 
-void launch_vertex_stage(hipStream_t s, const FrameParams* p, const float* vsoa, const float* inst_model, const float* inst_normal,
+void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa, const float* inst_model, const float* inst_normal,
                          VertexOut* out, uint32_t* counters, int n_verts, int n_instances) {
   dim3 grid((n_verts + 255) / 256, n_instances);
   hipLaunchKernelGGL(vertex_kernel, grid, dim3(256), 0, s, p, vsoa, inst_model, inst_normal, out, counters, n_verts);
 }
 
-void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
+void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           int n_tris, int n_instances) {
   // tile_count is zero on entry (the raster kernel of the previous frame clears it) and the vertex
@@ -404,9 +446,9 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams* p, const VertexOut* 
   hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, s, p, vout, indices, bt, n_tris);
 }
 
-void launch_raster(hipStream_t s, const FrameParams* p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* tile_flags, uint32_t* tile_list, bool write_empty,
-                   int tiles_x, int tiles_y) {
+void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* row_pairs, bool write_empty,
+                   const DevCube& sky_bordered, uint8_t* rgba8, int tiles_x, int tiles_y) {
   hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
-                     tile_flags, tile_list, write_empty ? 1 : 0);
+                     row_pairs, write_empty ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8));
 }

@@ -17,6 +17,7 @@
 // lookups are trilinear with the Vulkan face-selection / derivative transform and seamless edges.
 #include "pbr_internal.h"
 #include "devmath.h"
+#include "sky_shade.h"
 
 namespace {
 
@@ -108,16 +109,6 @@ PBR_DEV float2 sample_lut(const uint16_t* lut, int size, uint32_t sampler, float
 }
 
 // ---------------- cube maps ----------------
-struct CubeCoord { int face; float sc, tc, rc; };
-
-PBR_DEV CubeCoord cube_select(V3 r) {
-  const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
-  CubeCoord c;
-  if (az >= ax && az >= ay) { c.face = r.z >= 0 ? 4 : 5; c.sc = r.z >= 0 ? r.x : -r.x; c.tc = -r.y; c.rc = r.z; }
-  else if (ay >= ax)        { c.face = r.y >= 0 ? 2 : 3; c.sc = r.x; c.tc = r.y >= 0 ? r.z : -r.z; c.rc = r.y; }
-  else                      { c.face = r.x >= 0 ? 0 : 1; c.sc = r.x >= 0 ? -r.z : r.z; c.tc = -r.y; c.rc = r.x; }
-  return c;
-}
 PBR_DEV void cube_table(int face, V3 d, float& sc, float& tc, float& rc) {
   switch (face) {
     case 0: sc = -d.z; tc = -d.y; rc = d.x; break;
@@ -369,13 +360,6 @@ PBR_DEV Eval eval_invocation(const FrameParams* p, const ResolveInputs& in, cons
 
 PBR_DEV float smith_ggx(float c, float k) { return c * rcp_fast(c * (1.0f - k) + k); }   // shader.wgsl:83-91
 
-PBR_DEV uint32_t pack_color(V3 color) {
-  // pow(c, 1/2.2) as exp2(log2(c) / 2.2) (shader.wgsl:157, skybox.wgsl:30): 0 -> 0, negative or NaN -> NaN -> 0
-  const float g = 1.0f / 2.2f;
-  return to_unorm8(exp2_fast(log2_fast(color.x) * g)) | (to_unorm8(exp2_fast(log2_fast(color.y) * g)) << 8) |
-         (to_unorm8(exp2_fast(log2_fast(color.z) * g)) << 16) | 0xff000000u;
-}
-
 // fs_main after the derivative-dependent part (shader.wgsl:95, :108-159) for one owned pixel.
 template <bool FAST>
 PBR_DEV uint32_t shade_owned(const FrameParams* p, const ResolveInputs& in, const QuadShared& q, const Varyings& f, const Eval& fc, const Footprint& fp,
@@ -448,8 +432,9 @@ PBR_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src), __shfl(v.y, src), 
 // One thread per covered pixel.  Lanes 4q..4q+3 of a wavefront are the pixels (0,0), (1,0), (0,1),
 // (1,1) of quad q; a wavefront covers 32 x 2 pixels, a workgroup 32 x 8.
 template <bool FAST>
-__global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams* __restrict__ p, ResolveInputs in, const float* __restrict__ srgb_lut,
+__global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams frame_params, ResolveInputs in, const float* __restrict__ srgb_lut,
                                                               const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8) {
+  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ float s_srgb[256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & 3, quad = lane >> 2;
@@ -537,59 +522,6 @@ __global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams*
 // vertices, all material texels (own pixel and helpers), all IBL texels — instead of one round per
 // lookup: the kernel is latency-bound, so the number of dependent rounds sets its speed.
 // ---------------------------------------------------------------------------------------------
-struct CubeFoot { uint32_t o[4]; float w[4]; };
-
-// Texel offsets (from cube.base) and weights of one seamless bilinear lookup on one level.
-PBR_DEV CubeFoot cube_foot(const DevCube& cube, int level, const CubeCoord& c) {
-  CubeFoot f;
-  const int n = max(1, cube.size >> level);
-  const uint32_t base = cube.off[level];
-  const float ima = rcp_fast(fabsf(c.rc));
-  const float s = 0.5f * (c.sc * ima) + 0.5f, t = 0.5f * (c.tc * ima) + 0.5f;
-  const float tu = s * (float)n - 0.5f, tv = t * (float)n - 0.5f;
-  const float fu = floorf(tu), fv = floorf(tv), a = tu - fu, b = tv - fv;
-  const int i0 = (int)fu, j0 = (int)fv;
-  f.w[0] = (1.0f - a) * (1.0f - b); f.w[1] = a * (1.0f - b); f.w[2] = (1.0f - a) * b; f.w[3] = a * b;
-  if (i0 >= 0 && j0 >= 0 && i0 + 1 < n && j0 + 1 < n) {
-    const uint32_t o = base + ((uint32_t)c.face * n + j0) * n + i0;
-    f.o[0] = o; f.o[1] = o + 1; f.o[2] = o + n; f.o[3] = o + n + 1;
-    return f;
-  }
-  int missing = -1;
-  uint32_t valid = base;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    int i = i0 + (k & 1), j = j0 + (k >> 1), face = c.face;
-    const bool ox = i < 0 || i >= n, oy = j < 0 || j >= n;
-    if (ox && oy) { missing = k; f.o[k] = base; continue; }   // beyond a corner: no such texel
-    if (ox || oy) {
-      const float sc = ((float)i + 0.5f) / (float)n * 2.0f - 1.0f, tc = ((float)j + 0.5f) / (float)n * 2.0f - 1.0f;
-      const CubeCoord cc = cube_select(cube_dir(face, sc, tc));
-      const float im = rcp_fast(fabsf(cc.rc));
-      face = cc.face;
-      i = min(max((int)floorf((0.5f * (cc.sc * im) + 0.5f) * (float)n), 0), n - 1);
-      j = min(max((int)floorf((0.5f * (cc.tc * im) + 0.5f) * (float)n), 0), n - 1);
-    }
-    f.o[k] = base + ((uint32_t)face * n + j) * n + i;
-    valid = f.o[k];
-  }
-  if (missing >= 0) {   // the missing corner tap is the mean of the other three: its weight is shared out
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k == missing) continue;
-      f.w[k] += (missing == 0 ? f.w[0] : missing == 1 ? f.w[1] : missing == 2 ? f.w[2] : f.w[3]) * (1.0f / 3.0f);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (k == missing) { f.w[k] = 0.0f; f.o[k] = valid; }
-  }
-  return f;
-}
-
-PBR_DEV V3 weigh4(const float4 t[4], const float w[4]) {
-  return v3(((t[0].x * w[0] + t[1].x * w[1]) + t[2].x * w[2]) + t[3].x * w[3], ((t[0].y * w[0] + t[1].y * w[1]) + t[2].y * w[2]) + t[3].y * w[3],
-            ((t[0].z * w[0] + t[1].z * w[1]) + t[2].z * w[2]) + t[3].z * w[3]);
-}
-
 template <bool SRGB>
 PBR_DEV V3 decode_fast(const uint32_t t[4], const Footprint& f, const float* s_srgb) {
   V3 r;
@@ -621,12 +553,13 @@ PBR_DEV void tbn_reflect(const FrameParams* p, const V3& T, const Varyings& v, V
   R = v3(r.x, r.y, -r.z);
 }
 
-// Shades the covered pixels of the 32 x 8 pixel block whose first pixel is (blk_x * 32, y0 + blk_y * 8).
-PBR_DEV void surface_fast_block(const FrameParams* __restrict__ p, const ResolveInputs& in, const float* s_srgb, const uint32_t* __restrict__ vis,
-                                uint32_t* __restrict__ rgba8, int blk_x, int blk_y) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One wavefront shades the covered pixels of a 32 x 2 pixel row pair whose first pixel is (x_first, y_first):
+// sixteen 2x2 quads, four consecutive lanes each.
+PBR_DEV void surface_fast_rows(const FrameParams* __restrict__ p, const ResolveInputs& in, const float* s_srgb, const uint32_t* __restrict__ vis,
+                               uint32_t* __restrict__ rgba8, int x_first, int y_first) {
+  const int lane = threadIdx.x & 63;
   const int sub = lane & 3, quad = lane >> 2;
-  const int qx = blk_x * 32 + quad * 2, qy = p->y0 + blk_y * 8 + wave * 2;
+  const int qx = x_first + quad * 2, qy = y_first;
   const int x = qx + (sub & 1), y = qy + (sub >> 1);
   const bool live = x < p->W && y < p->y1;
   const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
@@ -696,7 +629,7 @@ PBR_DEV void surface_fast_block(const FrameParams* __restrict__ p, const Resolve
   const V3 nd = v3(normal.x, normal.y, -normal.z);
   const bool bad_n = any_nan(nd), bad_r = any_nan(R);
   const CubeCoord cn = cube_select(bad_n ? v3(0, 0, 1) : nd), cr = cube_select(bad_r ? v3(0, 0, 1) : R);
-  const CubeFoot fi = cube_foot(in.irr, 0, cn), fa = cube_foot(in.pre, l0, cr), fb = cube_foot(in.pre, l1, cr);
+  const CubeFoot fi = cube_foot(in.irr_b, 0, cn), fa = cube_foot(in.pre_b, l0, cr), fb = cube_foot(in.pre_b, l1, cr);
   const int ls = in.lut_size;
   const float lu = ndotv * (float)ls - 0.5f, lv = roughness * (float)ls - 0.5f;
   const float lfu = floorf(lu), lfv = floorf(lv), la = lu - lfu, lb = lv - lfv;
@@ -706,8 +639,7 @@ PBR_DEV void surface_fast_block(const FrameParams* __restrict__ p, const Resolve
   else { lx0 = ((lx0 % ls) + ls) % ls; lx1 = ((lx1 % ls) + ls) % ls; ly0 = ((ly0 % ls) + ls) % ls; ly1 = ((ly1 % ls) + ls) % ls; }
   if (bad_lut) { lx0 = lx1 = ly0 = ly1 = 0; }
   float4 ti[4], ta[4], tb[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) { ti[k] = in.irr.base[fi.o[k]]; ta[k] = in.pre.base[fa.o[k]]; tb[k] = in.pre.base[fb.o[k]]; }
+  cube_load4(in.irr_b.base, fi, ti); cube_load4(in.pre_b.base, fa, ta); cube_load4(in.pre_b.base, fb, tb);
   const ushort4* lt = reinterpret_cast<const ushort4*>(in.lut);
   const ushort4 u00 = lt[(uint32_t)ly0 * ls + lx0], u10 = lt[(uint32_t)ly0 * ls + lx1], u01 = lt[(uint32_t)ly1 * ls + lx0], u11 = lt[(uint32_t)ly1 * ls + lx1];
 
@@ -765,67 +697,55 @@ PBR_DEV void surface_fast_block(const FrameParams* __restrict__ p, const Resolve
   if (cov) rgba8[o] = pack_color(v3(ambient.x + Lo.x + emissive.x, ambient.y + Lo.y + emissive.y, ambient.z + Lo.z + emissive.z));
 }
 
-// Work list driven: the rasteriser appends every tile that received a triangle to `tile_list`; each
-// workgroup strides over (tile, quarter) items, a quarter being 32 x 8 pixels.  Background-only
-// tiles — most of the frame — never start a wavefront here.
-__global__ void __launch_bounds__(256) resolve_surface_fast_kernel(const FrameParams* __restrict__ p, ResolveInputs in, const float* __restrict__ srgb_lut,
-                                                                   const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8,
-                                                                   const uint32_t* __restrict__ tile_list, const uint32_t* __restrict__ counters) {
+// Work list driven: the rasteriser appends every row pair (32 x 2 pixels of one tile) that holds a covered
+// pixel, and background rows never start a wavefront.  One workgroup per compute unit, as many
+// wavefronts as the unit holds; workgroup b owns items b, b + gridDim.x, ... and its waves claim them
+// one at a time from a counter in LDS, so the waves of a unit finish within one item of each other
+// whatever the item count.
+constexpr int kSurfaceThreads = 768;
+__global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(const FrameParams frame_params, ResolveInputs in,
+                                                                               const float* __restrict__ srgb_lut, const uint32_t* __restrict__ vis,
+                                                                               uint32_t* __restrict__ rgba8, const uint32_t* __restrict__ row_pairs,
+                                                                               const uint32_t* __restrict__ counters) {
+  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ float s_srgb[256];
-  s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
+  __shared__ uint32_t s_next;
+  if (threadIdx.x < 256) s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
+  if (threadIdx.x == 0) s_next = 0u;
   __syncthreads();
-  const uint32_t n_items = counters[6] * (PBR_TILE / 8);
-  for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const uint32_t tile = tile_list[item / (PBR_TILE / 8)];
+  const uint32_t n_items = counters[6];
+  const int lane = threadIdx.x & 63;
+  for (;;) {
+    uint32_t k = 0;
+    if (lane == 0) k = atomicAdd(&s_next, 1u);
+    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    const uint32_t item = blockIdx.x + k * gridDim.x;
+    if (item >= n_items) break;
+    const uint32_t it = row_pairs[item];
+    const uint32_t tile = it >> 4, pair = it & 15u;
     const int tx = (int)(tile % (uint32_t)p->tiles_x), ty = (int)(tile / (uint32_t)p->tiles_x);
-    surface_fast_block(p, in, s_srgb, vis, rgba8, tx, ty * (PBR_TILE / 8) + (int)(item % (PBR_TILE / 8)));
+    surface_fast_rows(p, in, s_srgb, vis, rgba8, tx * PBR_TILE, p->y0 + ty * PBR_TILE + (int)pair * 2);
   }
 }
 
-// Background pixels: fs_main of skybox.wgsl:24-33.  One workgroup per raster tile (32 x 32 pixels),
-// one thread per four horizontally adjacent pixels: sixteen independent cube taps in flight and one
-// 16-byte store.  A tile the rasteriser left empty is all background, so its visibility entries are
-// not even read.
-__global__ void __launch_bounds__(256) resolve_sky_kernel(const FrameParams* __restrict__ p, DevCube sky, const uint32_t* __restrict__ vis,
-                                                          const uint32_t* __restrict__ tile_flags, uint32_t* __restrict__ rgba8) {
-  const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
-  const int x0 = blockIdx.x * PBR_TILE + (threadIdx.x & 7) * 4, y = p->y0 + blockIdx.y * PBR_TILE + (threadIdx.x >> 3);
-  const int W = p->W;
-  if (x0 >= W || y >= p->y1) return;
-  const size_t o = (size_t)(y - p->y0) * W + x0;
-  const bool wide = x0 + 3 < W && (o & 3) == 0;
-  uint32_t id[4] = {0u, 0u, 0u, 0u};
-  if (tile_flags[tile] != 0u) {
-    if (wide) { const uint4 v = *reinterpret_cast<const uint4*>(vis + o); id[0] = v.x; id[1] = v.y; id[2] = v.z; id[3] = v.w; }
-    else { for (int k = 0; k < 4; ++k) if (x0 + k < W) id[k] = vis[o + k]; }
-    if (id[0] && id[1] && id[2] && id[3]) return;
+// Builds one level of a bordered cube (see cube_foot): [6][n + 2][n + 2] from [6][n][n].
+__global__ void __launch_bounds__(256) cube_border_kernel(DevCube src, int level, float4* __restrict__ dst) {
+  const int n = max(1, src.size >> level), m = n + 2;
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= 6u * m * m) return;
+  const int face = (int)(idx / (uint32_t)(m * m)), r = (int)(idx % (uint32_t)(m * m));
+  const int j = r / m - 1, i = r % m - 1;
+  const float4* lv = src.base + src.off[level];
+  float4 out;
+  if (!cube_tap(lv, n, face, i, j, out)) {
+    // beyond a corner there is no texel: a lookup there blends the three that exist
+    const int ci = min(max(i, 0), n - 1), cj = min(max(j, 0), n - 1);
+    float4 a, b, c;
+    cube_tap(lv, n, face, ci, cj, a); cube_tap(lv, n, face, i, cj, b); cube_tap(lv, n, face, ci, j, c);
+    out = make_float4(((a.x + b.x) + c.x) * (1.0f / 3.0f), ((a.y + b.y) + c.y) * (1.0f / 3.0f), ((a.z + b.z) + c.z) * (1.0f / 3.0f),
+                      ((a.w + b.w) + c.w) * (1.0f / 3.0f));
   }
-  const float* m = p->u.inv_view_proj;
-  const float yn = 1.0f - ((float)y + 0.5f) / (float)p->H * 2.0f;
-  CubeFoot foot[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float xn = ((float)(x0 + k) + 0.5f) / (float)W * 2.0f - 1.0f;
-    const float tx = ((m[0] * xn + m[4] * yn) + m[8]) + m[12];
-    const float ty = ((m[1] * xn + m[5] * yn) + m[9]) + m[13];
-    const float tz = ((m[2] * xn + m[6] * yn) + m[10]) + m[14];
-    const float tw = ((m[3] * xn + m[7] * yn) + m[11]) + m[15];
-    // normalize(xyz / w) only rescales the lookup direction by 1 / (w |xyz|); the cube lookup depends on
-    // the direction alone, so only the sign of w is applied.
-    const float sg = tw < 0.0f ? -1.0f : 1.0f;
-    foot[k] = cube_foot(sky, 0, cube_select(v3(tx * sg, ty * sg, -(tz * sg))));
-  }
-  float4 tap[4][4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tap[k][j] = sky.base[foot[k].o[j]];
-  uint32_t out[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) out[k] = pack_color(weigh4(tap[k], foot[k].w));
-  if (wide && !(id[0] | id[1] | id[2] | id[3])) { *reinterpret_cast<uint4*>(rgba8 + o) = make_uint4(out[0], out[1], out[2], out[3]); return; }
-#pragma unroll
-  for (int k = 0; k < 4; ++k) if (x0 + k < W && !id[k]) rgba8[o + k] = out[k];
+  dst[idx] = out;
 }
 
 // Number of covered pixels, for the frame statistics only: one atomic per 16384 pixels (a single
@@ -844,19 +764,28 @@ __global__ void __launch_bounds__(256) count_covered_kernel(const uint32_t* __re
 
 }  // namespace
 
-void launch_resolve(hipStream_t s, const FrameParams* p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    const uint32_t* tile_flags, const uint32_t* tile_list, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast,
-                    hipEvent_t between) {
+int surface_fast_blocks_per_cu() {
+  int blocks = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, resolve_surface_fast_kernel, kSurfaceThreads, 0) != hipSuccess || blocks < 1) blocks = 1;
+  return blocks;
+}
+
+void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
+                    const uint32_t* row_pairs, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks) {
   uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
-  hipLaunchKernelGGL(resolve_sky_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, in.sky, vis, tile_flags, out);
-  if (between) (void)hipEventRecord(between, s);   // separates the two kernels for per-kernel timing
   if (fast) {
-    const int blocks = std::min(tiles_x * tiles_y * (PBR_TILE / 8), 3072);
-    hipLaunchKernelGGL(resolve_surface_fast_kernel, dim3(blocks), dim3(256), 0, s, p, in, srgb_lut, vis, out, tile_list, counters);
+    // no more workgroups than the chip holds at once, and no more than there can be row pairs
+    const int blocks = std::max(1, std::min(tiles_x * tiles_y * (PBR_TILE / 2), resident_blocks));
+    hipLaunchKernelGGL(resolve_surface_fast_kernel, dim3(blocks), dim3(kSurfaceThreads), 0, s, p, in, srgb_lut, vis, out, row_pairs, counters);
   } else {
     dim3 grid((W + 31) / 32, (rows + 7) / 8);
     hipLaunchKernelGGL(resolve_surface_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis, out);
   }
+}
+
+void launch_cube_border(hipStream_t s, DevCube src, int level, float4* dst_level) {
+  const int n = std::max(1, src.size >> level), m = n + 2;
+  hipLaunchKernelGGL(cube_border_kernel, dim3((unsigned)((6u * m * m + 255u) / 256u)), dim3(256), 0, s, src, level, dst_level);
 }
 
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered) {
