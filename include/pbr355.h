@@ -76,7 +76,8 @@ typedef struct PbrFrameStats {
   uint32_t covered_pixels;   /* pixels whose visibility entry is a triangle */
   uint32_t binned_refs;      /* triangle-tile references that spilled past a tile's own bin row */
   uint32_t setup_triangles;  /* front-facing (sub)triangles after clipping and culling */
-  uint32_t reserved;
+  uint32_t uniform_quads;    /* 2x2 pixel quads whose four pixels show one triangle */
+  uint32_t mixed_quads;      /* quads with a covered pixel that are not uniform (edges, silhouettes) */
 } PbrFrameStats;
 
 /* ---- lifetime: replaces requestAdapter/requestDevice, renderer.ts:144-198 ---- */

@@ -15,6 +15,6 @@ for dist in (5.0, 3.5, 2.5, 1.8, 60.0):
     for _ in range(5):
         _, st = r.draw_frame(want_stats=True)
         if best is None or st.ms_total < best[0]:
-            best = (st.ms_total, st.ms_vertex, st.ms_setup, st.ms_raster, st.ms_resolve, st.covered_pixels, st.setup_triangles, st.binned_refs)
+            best = (st.ms_total, st.ms_vertex, st.ms_setup, st.ms_raster, st.ms_resolve, st.covered_pixels, st.setup_triangles, st.binned_refs, st.uniform_quads, st.mixed_quads)
     c = best[5] / (W * H)
-    print(f"dist {dist:5.1f} cover {c:.4f} total {best[0]*1e3:7.1f} us  vertex {best[1]*1e3:6.1f} setup+bin {best[2]*1e3:6.1f} raster {best[3]*1e3:6.1f} resolve {best[4]*1e3:6.1f}  tris {best[6]} refs {best[7]}", flush=True)
+    print(f"dist {dist:5.1f} cover {c:.4f} total {best[0]*1e3:7.1f} us  vertex {best[1]*1e3:6.1f} setup+bin {best[2]*1e3:6.1f} raster {best[3]*1e3:6.1f} resolve {best[4]*1e3:6.1f}  tris {best[6]} refs {best[7]} quads u {best[8]} m {best[9]}", flush=True)

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(pkg):
 
 def test_struct_layouts_match_header(pkg):
     assert C.sizeof(pkg._lib.FrameUniforms) == 5 * 64 + 16 + 64 + 64 + 16 + 16
-    assert C.sizeof(pkg._lib.FrameStats) == 36
+    assert C.sizeof(pkg._lib.FrameStats) == 40
 
 
 def test_no_silent_cpu_fallback(pkg):

@@ -23,7 +23,7 @@ class FrameUniforms(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [
         ("ms_vertex", C.c_float), ("ms_setup", C.c_float), ("ms_raster", C.c_float), ("ms_resolve", C.c_float), ("ms_total", C.c_float),
-        ("covered_pixels", C.c_uint32), ("binned_refs", C.c_uint32), ("setup_triangles", C.c_uint32), ("reserved", C.c_uint32),
+        ("covered_pixels", C.c_uint32), ("binned_refs", C.c_uint32), ("setup_triangles", C.c_uint32), ("uniform_quads", C.c_uint32), ("mixed_quads", C.c_uint32),
     ]
 
 

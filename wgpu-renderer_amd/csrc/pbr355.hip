@@ -140,6 +140,12 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
     HIP_TRY(c, hipMalloc(&c->d_vout, nv * sizeof(VertexOut)));
     c->vout_cap = nv; grew = true;
   }
+  if (ntri > c->record_cap) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_records);
+    HIP_TRY(c, hipMalloc(&c->d_records, ntri * sizeof(TriRecord)));
+    c->record_cap = ntri; grew = true;
+  }
   const size_t want_setup = ntri + ntri / 4 + 4096;
   if (want_setup > c->setup_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -152,8 +158,11 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
   }
   if ((size_t)n_tiles > c->tile_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->d_row_pairs);
-    HIP_TRY(c, hipMalloc(&c->d_row_pairs, sizeof(uint32_t) * (size_t)n_tiles * (PBR_TILE / 2)));
+    free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
+    const size_t n_quads = (size_t)n_tiles * (PBR_TILE / 2) * (PBR_TILE / 2);
+    HIP_TRY(c, hipMalloc(&c->quad_lists.uniform, sizeof(uint2) * n_quads));
+    HIP_TRY(c, hipMalloc(&c->quad_lists.mixed_pos, sizeof(uint32_t) * n_quads));
+    HIP_TRY(c, hipMalloc(&c->quad_lists.mixed_ids, sizeof(uint4) * n_quads));
     HIP_TRY(c, hipMalloc(&c->d_tile_count, sizeof(uint32_t) * n_tiles));
     HIP_TRY(c, hipMalloc(&c->d_bins, sizeof(uint32_t) * (size_t)n_tiles * PBR_BIN_CAP));
     HIP_TRY(c, hipMemset(c->d_tile_count, 0, sizeof(uint32_t) * n_tiles));   // kept clear from frame to frame by the raster kernel
@@ -267,7 +276,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
 
   launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
-  launch_setup_and_bin(s, dp, c->d_vout, c->d_indices, c->d_setup, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
+  launch_setup_and_bin(s, dp, c->d_vout, c->d_indices, c->d_setup, c->d_records, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
                        (uint32_t)c->overflow_cap, c->d_counters, c->n_indices / 3, c->n_instances);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   // the specialised resolve covers the reference's default sampler on power-of-two textures
@@ -278,21 +287,21 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     fast = fast && (c->tex[i].w & (c->tex[i].w - 1)) == 0 && (c->tex[i].h & (c->tex[i].h - 1)) == 0 && c->tex[i].w == c->tex[0].w &&
            c->tex[i].h == c->tex[0].h && c->tex[i].levels == c->tex[0].levels;
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
-  // the visibility entries of tiles without geometry are only written when someone will read them:
-  // the caller (vis output), the coverage count of the statistics, or the general-sampler resolve
-  const bool write_empty = d_vis != nullptr || want_host_vis || timed || !fast;
+  // the visibility buffer is only written when someone will read it: the caller (vis output), the
+  // coverage count of the statistics, or the general-sampler resolve
+  const bool write_vis = d_vis != nullptr || want_host_vis || timed || !fast;
   launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
-                c->d_counters, c->d_row_pairs, write_empty, pr->sky_b.cube, color, tiles_x, tiles_y);
+                c->d_counters, c->quad_lists, write_vis, pr->sky_b.cube, color, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
 
   ResolveInputs in;
-  in.vout = c->d_vout; in.indices = c->d_indices;
+  in.records = c->d_records; in.vout = c->d_vout; in.indices = c->d_indices;
   for (int i = 0; i < 5; ++i) in.tex[i] = c->tex[i];
   in.irr = c->irr; in.pre = c->pre; in.sky = c->sky;
   in.irr_b = pr->irr_b.cube; in.pre_b = pr->pre_b.cube; in.sky_b = pr->sky_b.cube;
   in.lut = c->d_lut; in.lut_size = c->lut_size;
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
-  launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->d_row_pairs, c->d_counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
+  launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->quad_lists, c->d_counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
@@ -312,7 +321,8 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     stats->setup_triangles = c->h_counters[0];
     stats->binned_refs = c->h_counters[1];   // references that spilled past a tile's own row
     stats->covered_pixels = c->h_counters[3];
-    stats->reserved = 0;
+    stats->uniform_quads = c->h_counters[6];
+    stats->mixed_quads = c->h_counters[7];
     return check_sticky(c);
   }
   return PBR_OK;
@@ -375,7 +385,7 @@ int pbr_destroy(PbrContext* c) {
   free_dev(c->d_hdr); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
   { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); }
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
-  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->d_row_pairs);
+  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
   free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
   free_dev(pr->d_srgb_lut);
   if (c->h_counters) (void)hipHostFree(c->h_counters);

@@ -51,11 +51,29 @@ struct SetupTri {
   uint32_t pad;
 };
 
+// Everything the shading resolve needs of one triangle, written by the setup kernel so that a pixel
+// fetches it in one round of loads: 36 words, read as nine 16-byte loads.
+struct TriRecord {
+  int32_t X0, Y0, X1, Y1, X2, Y2;   // vertices snapped to 1/256 pixel, in index order (valid when projective)
+  float inv_area;                   // 1 / (twice the signed area in snapped units)
+  uint32_t projective;              // all w > 0 and inside the guard band: screen-space barycentrics apply
+  float iw0, iw1, iw2, pad;         // 1 / w of the vertices
+  float pos[9], nrm[9], uv[6];      // world positions, transformed normals, texcoords of the three vertices
+};
+
 // Per-vertex outputs of the vertex stage, laid out for the resolve's gathers.
 struct VertexOut {
   float4 clip;      // projection * view * model * position
   float4 world_u;   // world position xyz, texcoord u
   float4 nrm_v;     // normal-matrix * normal xyz, texcoord v
+};
+
+// Work lists the rasteriser leaves for the shading resolve: 2x2 pixel quads holding geometry.  pos is
+// (x / 2) | (row-in-range / 2) << 16.
+struct QuadLists {
+  uint2* uniform;       // (pos, id): all four pixels show triangle id - 1
+  uint32_t* mixed_pos;  // quads with several triangles or background pixels ...
+  uint4* mixed_ids;     // ... and the ids of their pixels (0,0), (1,0), (0,1), (1,1); 0 = background
 };
 
 struct FrameParams {
@@ -100,10 +118,11 @@ struct PbrContext {
   // frame working set (grown on demand)
   VertexOut* d_vout = nullptr;    size_t vout_cap = 0;
   SetupTri* d_setup = nullptr;    size_t setup_cap = 0;
+  TriRecord* d_records = nullptr; size_t record_cap = 0;   // one per triangle of every instance
   uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0;   // [tiles], [tiles][PBR_BIN_CAP]
-  uint32_t* d_row_pairs = nullptr;                                                     // work list of the resolve: tile * 16 + row pair, [tiles * 16]
+  QuadLists quad_lists = {nullptr, nullptr, nullptr};                                  // work lists of the resolve, each [tiles * 256]
   uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
-  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6] row pairs holding geometry
+  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6], [7] uniform and mixed quads holding geometry
   bool capture_depth = false;
   uint32_t* h_counters = nullptr; // pinned mirror
   uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0;
@@ -129,13 +148,14 @@ void launch_brdf_lut(hipStream_t s, uint16_t* out, int size);
 
 void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa, const float* inst_model, const float* inst_normal,
                          VertexOut* out, uint32_t* counters, int n_verts, int n_instances);
-void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
+void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           int n_tris, int n_instances);
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* row_pairs, bool write_empty,
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, const QuadLists& lists, bool write_vis,
                    const DevCube& sky_bordered, uint8_t* rgba8, int tiles_x, int tiles_y);
 struct ResolveInputs {
+  const TriRecord* records;
   const VertexOut* vout;
   const uint16_t* indices;
   DevTex8 tex[5];
@@ -146,7 +166,7 @@ struct ResolveInputs {
 };
 // covered pixels; the rasteriser has already written the skybox colour of the background pixels
 void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    const uint32_t* row_pairs, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks);
+                    const QuadLists& lists, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks);
 int surface_fast_blocks_per_cu();
 void launch_cube_border(hipStream_t s, DevCube src, int level, float4* dst_level);
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered);

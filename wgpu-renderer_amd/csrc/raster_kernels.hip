@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) vertex_kernel(const FrameParams frame_par
   const int inst = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
   // first kernel of a frame: re-arm the setup-triangle and bin-overflow counters the later kernels append with
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { counters[0] = 0u; counters[1] = 0u; counters[6] = 0u; }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { counters[0] = 0u; counters[1] = 0u; counters[6] = 0u; counters[7] = 0u; }
   if (i >= n_verts) return;
   float model[16], nmat[16], pvm[16];
   const float* msrc = p->has_instance_mats ? inst_model + 16 * inst : p->u.model;
@@ -96,6 +96,7 @@ struct BinTargets {
   uint32_t* tile_count; uint32_t* bins;
   uint2* overflow; uint32_t overflow_cap;
   uint32_t* counters;
+  TriRecord* records;
 };
 
 PBR_DEV void bin_store(const BinTargets& bt, uint32_t tile, uint32_t pos, uint32_t slot) {
@@ -151,10 +152,38 @@ PBR_DEV void emit_triangle(uint32_t id, float4 a, float4 b, float4 c, const Fram
   for (int first = 0; first < n_tiles; first += 4) bin_four(p, bt, box.tx0, box.ty0, bw, n_tiles, first, slot);
 }
 
+// The triangle as the shading resolve wants it.  The snapped coordinates are the rasteriser's own (same
+// arithmetic), so the barycentrics of a pixel agree with the coverage test that produced it.
+PBR_DEV void write_record(TriRecord* __restrict__ dst, const VertexOut& a, const VertexOut& b, const VertexOut& c, int W, int H) {
+  const float4 ca = a.clip, cb = b.clip, cc = c.clip;
+  bool projective = ca.w > 0.0f && cb.w > 0.0f && cc.w > 0.0f && fabsf(ca.x) <= mul_rn(PBR_GUARD, ca.w) && fabsf(ca.y) <= mul_rn(PBR_GUARD, ca.w) &&
+                    fabsf(cb.x) <= mul_rn(PBR_GUARD, cb.w) && fabsf(cb.y) <= mul_rn(PBR_GUARD, cb.w) && fabsf(cc.x) <= mul_rn(PBR_GUARD, cc.w) &&
+                    fabsf(cc.y) <= mul_rn(PBR_GUARD, cc.w);
+  int X0 = 0, Y0 = 0, X1 = 0, Y1 = 0, X2 = 0, Y2 = 0;
+  float inv_area = 0.0f;
+  if (projective) {
+    const Snapped s0 = snap_vertex(ca, W, H), s1 = snap_vertex(cb, W, H), s2 = snap_vertex(cc, W, H);
+    X0 = s0.X; Y0 = s0.Y; X1 = s1.X; Y1 = s1.Y; X2 = s2.X; Y2 = s2.Y;
+    const long long area = (long long)(X1 - X0) * (Y2 - Y0) - (long long)(X2 - X0) * (Y1 - Y0);
+    if (area == 0) projective = false; else inv_area = rcp_fast((float)area);
+  }
+  float4* d = reinterpret_cast<float4*>(dst);
+  d[0] = make_float4(__int_as_float(X0), __int_as_float(Y0), __int_as_float(X1), __int_as_float(Y1));
+  d[1] = make_float4(__int_as_float(X2), __int_as_float(Y2), inv_area, __int_as_float(projective ? 1 : 0));
+  d[2] = make_float4(rcp_fast(ca.w), rcp_fast(cb.w), rcp_fast(cc.w), 0.0f);
+  d[3] = make_float4(a.world_u.x, a.world_u.y, a.world_u.z, b.world_u.x);
+  d[4] = make_float4(b.world_u.y, b.world_u.z, c.world_u.x, c.world_u.y);
+  d[5] = make_float4(c.world_u.z, a.nrm_v.x, a.nrm_v.y, a.nrm_v.z);
+  d[6] = make_float4(b.nrm_v.x, b.nrm_v.y, b.nrm_v.z, c.nrm_v.x);
+  d[7] = make_float4(c.nrm_v.y, c.nrm_v.z, a.world_u.w, a.nrm_v.w);
+  d[8] = make_float4(b.world_u.w, b.nrm_v.w, c.world_u.w, c.nrm_v.w);
+}
+
 PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint16_t* indices, const BinTargets& bt, int inst, int t, int n_tris,
                        Deferred* defer) {
   const size_t base = (size_t)inst * p->n_verts;
-  const float4 a = vout[base + indices[3 * t]].clip, b = vout[base + indices[3 * t + 1]].clip, c = vout[base + indices[3 * t + 2]].clip;
+  const VertexOut va = vout[base + indices[3 * t]], vb = vout[base + indices[3 * t + 1]], vc = vout[base + indices[3 * t + 2]];
+  const float4 a = va.clip, b = vb.clip, c = vc.clip;
   const uint32_t id = (uint32_t)inst * (uint32_t)n_tris + (uint32_t)t;
   const float4 v[3] = {a, b, c};
   bool inside_all = true;
@@ -172,6 +201,7 @@ PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint16
     for (int k = 0; k < 3; ++k) { l += v[k].x < -v[k].w; r += v[k].x > v[k].w; bt_ += v[k].y < -v[k].w; tp += v[k].y > v[k].w; }
     if (l == 3 || r == 3 || bt_ == 3 || tp == 3) return;   // beside the viewport: no pixel centre can be covered
   }
+  write_record(bt.records + id, va, vb, vc, p->W, p->H);
   if (inside_all) { emit_triangle(id, a, b, c, p, bt, defer); return; }
   // Rare path: Sutherland-Hodgman against the six planes, then a fan from the first vertex.
   float4 poly[12], tmp[12];
@@ -242,11 +272,11 @@ PBR_DEV long long bcast64(long long v, int src_lane) {
 __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_params, const SetupTri* __restrict__ setup,
                                                      uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
                                                      const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
-                                                     float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ row_pairs,
-                                                     int write_empty, DevCube sky, uint32_t* __restrict__ rgba8) {
+                                                     float* __restrict__ depth, uint32_t* __restrict__ counters, QuadLists lists, int write_vis, DevCube sky,
+                                                     uint32_t* __restrict__ rgba8) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
-  __shared__ uint32_t s_pairs[4];
+  __shared__ uint32_t s_pairs[4], s_base[2];
   const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int px0 = blockIdx.x * PBR_TILE, py0 = p->y0 + blockIdx.y * PBR_TILE;   // tile origin in pixels
@@ -377,8 +407,9 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
   if (inside) {
     const size_t o = (size_t)(y - p->y0) * p->W + x;
     const bool wide = x + 3 <= xmax && (o & 3) == 0;
-    // the visibility entries of a tile without geometry are only written when someone will read them
-    if (n != 0u || write_empty) {
+    // the visibility buffer is only written when someone will read it (the caller, the statistics, the
+    // general-sampler resolve); the specialised resolve works from the quad lists
+    if (write_vis) {
       if (wide) {
         *reinterpret_cast<uint4*>(vis + o) = make_uint4(ids[0], ids[1], ids[2], ids[3]);
         if (depth) *reinterpret_cast<float4*>(depth + o) = make_float4(zs[0], zs[1], zs[2], zs[3]);
@@ -402,27 +433,44 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
   }
   if (n == 0u) return;
 
-  // Work list for the shading resolve: one item per pair of pixel rows of this tile (32 x 2 pixels, the
-  // footprint of one resolve wavefront) that holds at least one covered pixel.  A wave here owns eight
-  // rows, sixteen lanes per row pair; one append per tile.
-  const unsigned long long covered = __ballot((ids[0] | ids[1] | ids[2] | ids[3]) != 0u);
-  if (lane == 0) {
-    uint32_t m = 0;
+  // Work lists for the shading resolve, one entry per 2x2 pixel quad that holds a covered pixel.  A quad
+  // whose four pixels show one triangle goes to the uniform list (position, id): its derivatives are
+  // differences between its own four invocations.  Any other quad goes to the mixed list (position,
+  // four ids): each of its covered pixels has to evaluate its triangle at the neighbouring pixels
+  // itself.  The thread of an even row owns the two quads it shares with the thread one row below
+  // (eight lanes further on); the lists are appended with two atomics per tile.
+  uint32_t below[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if ((covered >> (16 * k)) & 0xffffull) m |= 1u << k;
-    s_pairs[wave] = m;
+  for (int k = 0; k < 4; ++k) below[k] = (uint32_t)__shfl_down((int)ids[k], 8);
+  const bool owner = inside && !(ty & 1);
+  bool uni[2], mix[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t a = ids[2 * q], b = ids[2 * q + 1], c = below[2 * q], d = below[2 * q + 1];
+    const bool any = owner && (a | b | c | d) != 0u;
+    uni[q] = any && a == b && a == c && a == d;
+    mix[q] = any && !uni[q];
   }
+  const unsigned long long bu0 = __ballot(uni[0]), bu1 = __ballot(uni[1]), bm0 = __ballot(mix[0]), bm1 = __ballot(mix[1]);
+  const unsigned long long lower = (1ull << lane) - 1ull;
+  if (lane == 0) s_pairs[wave] = (uint32_t)(__popcll(bu0) + __popcll(bu1)) | ((uint32_t)(__popcll(bm0) + __popcll(bm1)) << 16);
   __syncthreads();
   if (tid == 0) {
-    uint32_t mask = s_pairs[0] | (s_pairs[1] << 4) | (s_pairs[2] << 8) | (s_pairs[3] << 12);
-    if (mask) {
-      uint32_t at = atomicAdd(&counters[6], (uint32_t)__popc(mask));
-      while (mask) {
-        const int pair = __ffs((int)mask) - 1;
-        mask &= mask - 1;
-        row_pairs[at++] = (uint32_t)tile * 16u + (uint32_t)pair;
-      }
-    }
+    const uint32_t tu = (s_pairs[0] & 0xffffu) + (s_pairs[1] & 0xffffu) + (s_pairs[2] & 0xffffu) + (s_pairs[3] & 0xffffu);
+    const uint32_t tm = (s_pairs[0] >> 16) + (s_pairs[1] >> 16) + (s_pairs[2] >> 16) + (s_pairs[3] >> 16);
+    s_base[0] = tu ? atomicAdd(&counters[6], tu) : 0u;
+    s_base[1] = tm ? atomicAdd(&counters[7], tm) : 0u;
+  }
+  __syncthreads();
+  uint32_t at_u = s_base[0], at_m = s_base[1];
+  for (int w = 0; w < wave; ++w) { at_u += s_pairs[w] & 0xffffu; at_m += s_pairs[w] >> 16; }
+  at_u += (uint32_t)(__popcll(bu0 & lower) + __popcll(bu1 & lower));
+  at_m += (uint32_t)(__popcll(bm0 & lower) + __popcll(bm1 & lower));
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const uint32_t pos = (uint32_t)((x >> 1) + q) | ((uint32_t)((y - p->y0) >> 1) << 16);
+    if (uni[q]) { lists.uniform[at_u] = make_uint2(pos, ids[2 * q]); ++at_u; }
+    if (mix[q]) { lists.mixed_pos[at_m] = pos; lists.mixed_ids[at_m] = make_uint4(ids[2 * q], ids[2 * q + 1], below[2 * q], below[2 * q + 1]); ++at_m; }
   }
 }
 
@@ -434,21 +482,21 @@ void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa,
   hipLaunchKernelGGL(vertex_kernel, grid, dim3(256), 0, s, p, vsoa, inst_model, inst_normal, out, counters, n_verts);
 }
 
-void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup,
+void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           int n_tris, int n_instances) {
   // tile_count is zero on entry (the raster kernel of the previous frame clears it) and the vertex
   // kernel has reset the append counters
   BinTargets bt;
   bt.setup = setup; bt.setup_cap = setup_cap; bt.tile_count = tile_count; bt.bins = bins; bt.overflow = overflow; bt.overflow_cap = overflow_cap;
-  bt.counters = counters;
+  bt.counters = counters; bt.records = records;
   dim3 grid((n_tris + 255) / 256, n_instances);
   hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, s, p, vout, indices, bt, n_tris);
 }
 
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* row_pairs, bool write_empty,
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, const QuadLists& lists, bool write_vis,
                    const DevCube& sky_bordered, uint8_t* rgba8, int tiles_x, int tiles_y) {
   hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
-                     row_pairs, write_empty ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8));
+                     lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8));
 }

@@ -553,39 +553,66 @@ PBR_DEV void tbn_reflect(const FrameParams* p, const V3& T, const Varyings& v, V
   R = v3(r.x, r.y, -r.z);
 }
 
-// One wavefront shades the covered pixels of a 32 x 2 pixel row pair whose first pixel is (x_first, y_first):
-// sixteen 2x2 quads, four consecutive lanes each.
-PBR_DEV void surface_fast_rows(const FrameParams* __restrict__ p, const ResolveInputs& in, const float* s_srgb, const uint32_t* __restrict__ vis,
-                               uint32_t* __restrict__ rgba8, int x_first, int y_first) {
-  const int lane = threadIdx.x & 63;
-  const int sub = lane & 3, quad = lane >> 2;
-  const int qx = x_first + quad * 2, qy = y_first;
-  const int x = qx + (sub & 1), y = qy + (sub >> 1);
-  const bool live = x < p->W && y < p->y1;
-  const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
-  const uint32_t id = live ? vis[o] : 0u;                                       // round 1
-  if (__ballot(id != 0u) == 0ull) return;
-  const int qbase = lane & ~3;
-  const uint32_t id0 = __shfl(id, qbase), id1 = __shfl(id, qbase + 1), id2 = __shfl(id, qbase + 2);
-  const bool need_explicit = id != 0u && !(id0 == id && id1 == id && id2 == id);
-  const bool any_explicit = __any(need_explicit);
-  const bool cov = id != 0u;
+// Value of lane SRC (0..3) of the caller's quad, as a DPP move: no LDS traffic, no wait.
+template <int SRC>
+PBR_DEV float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SRC * 0x55, 0xf, 0xf, false));
+}
+template <int SRC>
+PBR_DEV V3 quad_bcast3(V3 v) { return v3(quad_bcast<SRC>(v.x), quad_bcast<SRC>(v.y), quad_bcast<SRC>(v.z)); }
 
-  // rounds 2 and 3: indices, then the three vertices (background lanes read triangle 0; their results are unused)
-  uint32_t inst = 0, tri = cov ? id - 1u : 0u;
-  if (p->n_instances > 1) { inst = tri / (uint32_t)p->n_tris; tri -= inst * (uint32_t)p->n_tris; }
-  const VertexOut* vb = in.vout + (size_t)inst * p->n_verts;
-  const uint32_t i0 = in.indices[3 * tri], i1 = in.indices[3 * tri + 1], i2 = in.indices[3 * tri + 2];
-  const VertexOut v0 = vb[i0], v1 = vb[i1], v2 = vb[i2];
+// Four consecutive lanes shade the 2x2 pixel quad at (qx, qy); `id` is the lane's own visibility entry.
+// UNIFORM: the four pixels show one triangle, so the helper invocations the derivatives need are the
+// other three lanes and their values are read across lanes.  Otherwise every covered lane evaluates
+// its own triangle at the pixels (0,0), (1,0), (0,1) of the quad itself.
+template <bool UNIFORM>
+PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveInputs& in, const float* s_srgb, uint32_t* __restrict__ rgba8, int qx,
+                               int qy, uint32_t id, bool live) {
+  const int sub = threadIdx.x & 3;
+  const int x = qx + (sub & 1), y = qy + (sub >> 1);
+  const bool cov = live && id != 0u;
+  const size_t o = (size_t)(y - p->y0) * p->W + x;
+
+  // round 1: the triangle's record (idle lanes read triangle 0; their results are unused)
+  const uint32_t tri_id = cov ? id - 1u : 0u;
+  const float4* rec = reinterpret_cast<const float4*>(in.records + tri_id);
+  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7], r8 = rec[8];
   Tri t;
-  t.c0 = v0.clip; t.c1 = v1.clip; t.c2 = v2.clip;
-  t.p0 = v3(v0.world_u.x, v0.world_u.y, v0.world_u.z); t.p1 = v3(v1.world_u.x, v1.world_u.y, v1.world_u.z); t.p2 = v3(v2.world_u.x, v2.world_u.y, v2.world_u.z);
-  t.n0 = v3(v0.nrm_v.x, v0.nrm_v.y, v0.nrm_v.z); t.n1 = v3(v1.nrm_v.x, v1.nrm_v.y, v1.nrm_v.z); t.n2 = v3(v2.nrm_v.x, v2.nrm_v.y, v2.nrm_v.z);
-  t.t0 = make_float2(v0.world_u.w, v0.nrm_v.w); t.t1 = make_float2(v1.world_u.w, v1.nrm_v.w); t.t2 = make_float2(v2.world_u.w, v2.nrm_v.w);
-  const QuadBary qb = quad_bary(t, qx, qy, p->W, p->H);
-  const Varyings h0 = varyings_at(t, qb, qx, qy, 0, 0, p->W, p->H), h1 = varyings_at(t, qb, qx, qy, 1, 0, p->W, p->H),
-                 h2 = varyings_at(t, qb, qx, qy, 0, 1, p->W, p->H);
-  const Varyings f = sub == 0 ? h0 : sub == 1 ? h1 : sub == 2 ? h2 : varyings_at(t, qb, qx, qy, 1, 1, p->W, p->H);
+  t.p0 = v3(r3.x, r3.y, r3.z); t.p1 = v3(r3.w, r4.x, r4.y); t.p2 = v3(r4.z, r4.w, r5.x);
+  t.n0 = v3(r5.y, r5.z, r5.w); t.n1 = v3(r6.x, r6.y, r6.z); t.n2 = v3(r6.w, r7.x, r7.y);
+  t.t0 = make_float2(r7.z, r7.w); t.t1 = make_float2(r8.x, r8.y); t.t2 = make_float2(r8.z, r8.w);
+  QuadBary qb;
+  qb.projective = __float_as_int(r1.w) != 0;
+  if (qb.projective) {
+    const int X0 = __float_as_int(r0.x), Y0 = __float_as_int(r0.y), X1 = __float_as_int(r0.z), Y1 = __float_as_int(r0.w), X2 = __float_as_int(r1.x),
+              Y2 = __float_as_int(r1.y);
+    const long long px = (long long)qx * 256 + 128, py = (long long)qy * 256 + 128;
+    const int a0 = -(Y2 - Y1), b0 = X2 - X1, a1 = -(Y0 - Y2), b1 = X0 - X2;
+    const long long e0 = (long long)b0 * (py - Y1) + (long long)a0 * (px - X1);
+    const long long e1 = (long long)b1 * (py - Y2) + (long long)a1 * (px - X2);
+    const float inv_area = r1.z;
+    qb.l0 = (float)e0 * inv_area; qb.l1 = (float)e1 * inv_area;
+    qb.l0x = (float)(a0 * 256) * inv_area; qb.l0y = (float)(b0 * 256) * inv_area;
+    qb.l1x = (float)(a1 * 256) * inv_area; qb.l1y = (float)(b1 * 256) * inv_area;
+    qb.iw0 = r2.x; qb.iw1 = r2.y; qb.iw2 = r2.z;
+  } else {
+    // a vertex behind the eye or beyond the guard band (rare): the homogeneous form needs the clip positions
+    uint32_t inst = 0, tri = tri_id;
+    if (p->n_instances > 1) { inst = tri / (uint32_t)p->n_tris; tri -= inst * (uint32_t)p->n_tris; }
+    const VertexOut* vb = in.vout + (size_t)inst * p->n_verts;
+    t.c0 = vb[in.indices[3 * tri]].clip; t.c1 = vb[in.indices[3 * tri + 1]].clip; t.c2 = vb[in.indices[3 * tri + 2]].clip;
+  }
+  Varyings f, h0, h1, h2;
+  if constexpr (UNIFORM) {
+    f = varyings_at(t, qb, qx, qy, sub & 1, sub >> 1, p->W, p->H);
+    h0.pos = quad_bcast3<0>(f.pos); h1.pos = quad_bcast3<1>(f.pos); h2.pos = quad_bcast3<2>(f.pos);
+    h0.uv = make_float2(quad_bcast<0>(f.uv.x), quad_bcast<0>(f.uv.y));
+    h1.uv = make_float2(quad_bcast<1>(f.uv.x), quad_bcast<1>(f.uv.y));
+    h2.uv = make_float2(quad_bcast<2>(f.uv.x), quad_bcast<2>(f.uv.y));
+  } else {
+    h0 = varyings_at(t, qb, qx, qy, 0, 0, p->W, p->H); h1 = varyings_at(t, qb, qx, qy, 1, 0, p->W, p->H); h2 = varyings_at(t, qb, qx, qy, 0, 1, p->W, p->H);
+    f = sub == 0 ? h0 : sub == 1 ? h1 : sub == 2 ? h2 : varyings_at(t, qb, qx, qy, 1, 1, p->W, p->H);
+  }
   // quad-shared derivatives (shader.wgsl:97-102)
   const V3 q1 = h1.pos - h0.pos, q2 = h2.pos - h0.pos;
   const float2 duvdx = make_float2(h1.uv.x - h0.uv.x, h1.uv.y - h0.uv.y), duvdy = make_float2(h2.uv.x - h0.uv.x, h2.uv.y - h0.uv.y);
@@ -593,7 +620,7 @@ PBR_DEV void surface_fast_rows(const FrameParams* __restrict__ p, const ResolveI
   const DevTex8& tx0 = in.tex[0];
   const int level = lod_2d(tx0.w, tx0.h, p->u.use_mipmaps ? tx0.levels : 1, 15u, duvdx, duvdy).level;
 
-  // round 4: every material texel of this pixel, and the normal-map texels of the helper pixels
+  // round 3: every material texel of this pixel, and the normal-map texels of the helper pixels
   const Footprint fp = footprint_fast(tx0, level, f.uv.x, f.uv.y);
   uint32_t t_nrm[4], t_mr[4], t_alb[4], t_emi[4], t_occ[4], t_h0[4], t_h1[4], t_h2[4];
   load4(in.tex[PBR_TEX_NORMAL].base, fp, t_nrm);
@@ -602,15 +629,16 @@ PBR_DEV void surface_fast_rows(const FrameParams* __restrict__ p, const ResolveI
   load4(in.tex[PBR_TEX_EMISSIVE].base, fp, t_emi);
   load4(in.tex[PBR_TEX_OCCLUSION].base, fp, t_occ);
   Footprint fp0 = fp, fp1 = fp, fp2 = fp;
-  if (any_explicit) {
+  if constexpr (!UNIFORM) {
     fp0 = footprint_fast(tx0, level, h0.uv.x, h0.uv.y); fp1 = footprint_fast(tx0, level, h1.uv.x, h1.uv.y); fp2 = footprint_fast(tx0, level, h2.uv.x, h2.uv.y);
     load4(in.tex[PBR_TEX_NORMAL].base, fp0, t_h0); load4(in.tex[PBR_TEX_NORMAL].base, fp1, t_h1); load4(in.tex[PBR_TEX_NORMAL].base, fp2, t_h2);
   }
 
-  V3 normal, view_dir, R;
+  V3 normal, view_dir, R, R0, R1, R2;
   tbn_reflect(p, T, f, decode_fast<false>(t_nrm, fp, s_srgb), normal, view_dir, R);
-  V3 R0 = shfl3(R, qbase), R1 = shfl3(R, qbase + 1), R2 = shfl3(R, qbase + 2);
-  if (any_explicit && need_explicit) {
+  if constexpr (UNIFORM) {
+    R0 = quad_bcast3<0>(R); R1 = quad_bcast3<1>(R); R2 = quad_bcast3<2>(R);
+  } else {
     V3 n_, v_;
     tbn_reflect(p, T, h0, decode_fast<false>(t_h0, fp0, s_srgb), n_, v_, R0);
     tbn_reflect(p, T, h1, decode_fast<false>(t_h1, fp1, s_srgb), n_, v_, R1);
@@ -620,7 +648,7 @@ PBR_DEV void surface_fast_rows(const FrameParams* __restrict__ p, const ResolveI
   const V3 mr = decode_fast<false>(t_mr, fp, s_srgb);
   const float metalness = mr.z, roughness = mr.y;
 
-  // round 5: irradiance (one level), prefilter (two levels of the implicit LOD), BRDF table
+  // round 4: irradiance (one level), prefilter (two levels of the implicit LOD), BRDF table
   float lambda = cube_lambda(in.pre.size, R, R1 - R0, R2 - R0);
   if (isnan(lambda)) lambda = 0.0f;
   lambda = fminf(fmaxf(lambda, 0.0f), (float)(in.pre.levels - 1));
@@ -697,34 +725,42 @@ PBR_DEV void surface_fast_rows(const FrameParams* __restrict__ p, const ResolveI
   if (cov) rgba8[o] = pack_color(v3(ambient.x + Lo.x + emissive.x, ambient.y + Lo.y + emissive.y, ambient.z + Lo.z + emissive.z));
 }
 
-// Work list driven: the rasteriser appends every row pair (32 x 2 pixels of one tile) that holds a covered
-// pixel, and background rows never start a wavefront.  One workgroup per compute unit, as many
-// wavefronts as the unit holds; workgroup b owns items b, b + gridDim.x, ... and its waves claim them
-// one at a time from a counter in LDS, so the waves of a unit finish within one item of each other
-// whatever the item count.
+// Work list driven: the rasteriser leaves two lists of 2x2 pixel quads that hold geometry, and background
+// pixels never start a wavefront here.  An item is sixteen quads of one list (one wavefront, four
+// lanes per quad); the mixed quads, the costlier ones, come first.  One workgroup per compute unit, as
+// many wavefronts as the unit holds; workgroup b owns items b, b + gridDim.x, ... and its waves claim
+// them one at a time from a counter in LDS, so the waves of a unit finish within one item of each other.
 constexpr int kSurfaceThreads = 768;
 __global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(const FrameParams frame_params, ResolveInputs in,
-                                                                               const float* __restrict__ srgb_lut, const uint32_t* __restrict__ vis,
-                                                                               uint32_t* __restrict__ rgba8, const uint32_t* __restrict__ row_pairs,
-                                                                               const uint32_t* __restrict__ counters) {
+                                                                               const float* __restrict__ srgb_lut, uint32_t* __restrict__ rgba8,
+                                                                               QuadLists lists, const uint32_t* __restrict__ counters) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ float s_srgb[256];
   __shared__ uint32_t s_next;
   if (threadIdx.x < 256) s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
   if (threadIdx.x == 0) s_next = 0u;
   __syncthreads();
-  const uint32_t n_items = counters[6];
+  const uint32_t n_uniform = counters[6], n_mixed = counters[7];
+  const uint32_t items_mixed = (n_mixed + 15u) >> 4, items = items_mixed + ((n_uniform + 15u) >> 4);
   const int lane = threadIdx.x & 63;
   for (;;) {
     uint32_t k = 0;
     if (lane == 0) k = atomicAdd(&s_next, 1u);
     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
     const uint32_t item = blockIdx.x + k * gridDim.x;
-    if (item >= n_items) break;
-    const uint32_t it = row_pairs[item];
-    const uint32_t tile = it >> 4, pair = it & 15u;
-    const int tx = (int)(tile % (uint32_t)p->tiles_x), ty = (int)(tile / (uint32_t)p->tiles_x);
-    surface_fast_rows(p, in, s_srgb, vis, rgba8, tx * PBR_TILE, p->y0 + ty * PBR_TILE + (int)pair * 2);
+    if (item >= items) break;
+    if (item >= items_mixed) {
+      const uint32_t q = (item - items_mixed) * 16u + (uint32_t)(lane >> 2);
+      const bool live = q < n_uniform;
+      const uint2 e = lists.uniform[live ? q : 0u];
+      surface_fast_quad<true>(p, in, s_srgb, rgba8, (int)(e.x & 0xffffu) * 2, p->y0 + (int)(e.x >> 16) * 2, e.y, live);
+    } else {
+      const uint32_t q = item * 16u + (uint32_t)(lane >> 2);
+      const bool live = q < n_mixed;
+      const uint32_t pos = lists.mixed_pos[live ? q : 0u];
+      const uint32_t id = reinterpret_cast<const uint32_t*>(lists.mixed_ids)[(live ? q : 0u) * 4u + (uint32_t)(lane & 3)];
+      surface_fast_quad<false>(p, in, s_srgb, rgba8, (int)(pos & 0xffffu) * 2, p->y0 + (int)(pos >> 16) * 2, id, live);
+    }
   }
 }
 
@@ -771,12 +807,12 @@ int surface_fast_blocks_per_cu() {
 }
 
 void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    const uint32_t* row_pairs, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks) {
+                    const QuadLists& lists, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks) {
   uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
   if (fast) {
-    // no more workgroups than the chip holds at once, and no more than there can be row pairs
-    const int blocks = std::max(1, std::min(tiles_x * tiles_y * (PBR_TILE / 2), resident_blocks));
-    hipLaunchKernelGGL(resolve_surface_fast_kernel, dim3(blocks), dim3(kSurfaceThreads), 0, s, p, in, srgb_lut, vis, out, row_pairs, counters);
+    // no more workgroups than the chip holds at once, and no more than there can be items
+    const int blocks = std::max(1, std::min(tiles_x * tiles_y * 16, resident_blocks));
+    hipLaunchKernelGGL(resolve_surface_fast_kernel, dim3(blocks), dim3(kSurfaceThreads), 0, s, p, in, srgb_lut, out, lists, counters);
   } else {
     dim3 grid((W + 31) / 32, (rows + 7) / 8);
     hipLaunchKernelGGL(resolve_surface_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis, out);

@@ -256,7 +256,8 @@ napi_value DrawFrame(napi_env env, napi_callback_info info) {
   NAPI_OK_OR_RETURN(napi_create_object(env, &obj));
   const struct { const char* name; double value; } fields[] = {
       {"msVertex", st.ms_vertex}, {"msSetup", st.ms_setup}, {"msRaster", st.ms_raster}, {"msResolve", st.ms_resolve}, {"msTotal", st.ms_total},
-      {"coveredPixels", (double)st.covered_pixels}, {"spilledRefs", (double)st.binned_refs}, {"setupTriangles", (double)st.setup_triangles}};
+      {"coveredPixels", (double)st.covered_pixels}, {"spilledRefs", (double)st.binned_refs}, {"setupTriangles", (double)st.setup_triangles},
+      {"uniformQuads", (double)st.uniform_quads}, {"mixedQuads", (double)st.mixed_quads}};
   for (const auto& f : fields) { napi_create_double(env, f.value, &v); napi_set_named_property(env, obj, f.name, v); }
   return obj;
 }

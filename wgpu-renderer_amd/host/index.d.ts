@@ -49,7 +49,7 @@ export class HDRLoader {
 
 export type FrameStats = {
   msVertex: number; msSetup: number; msRaster: number; msResolve: number; msTotal: number;
-  coveredPixels: number; spilledRefs: number; setupTriangles: number;
+  coveredPixels: number; spilledRefs: number; setupTriangles: number; uniformQuads: number; mixedQuads: number;
 };
 
 export type Frame = { rgba: Uint8Array; vis?: Uint32Array; stats: FrameStats };
