@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpbr355.so")
+LIB_PATH = os.environ.get("PBR355_LIBRARY") or os.path.join(_HERE, "libpbr355.so")   # the variable selects another build of the same library
 
 PBR_OK, PBR_E_ARG, PBR_E_STATE, PBR_E_DEVICE, PBR_E_UNSUPPORTED = 0, -1, -2, -3, -4
 TEX_ALBEDO, TEX_METALLIC_ROUGHNESS, TEX_NORMAL, TEX_EMISSIVE, TEX_OCCLUSION = range(5)

@@ -2,6 +2,7 @@
 // the small per-call tables on the host and enqueues the gfx950 kernels on the context's stream.
 // There is no CPU fallback: every entry point needs a HIP device.
 #include "pbr_internal.h"
+#include "sky_shade.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
@@ -274,10 +275,20 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], s));
   uint8_t* color = static_cast<uint8_t*>(d_rgba8);
 
-  launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances);
+  // The skybox tiles are shared out over the frame's three geometry launches: the vertex and setup
+  // kernels are latency-bound and leave the chip almost idle, so each carries a slice of the tiles as
+  // extra workgroups; the rasteriser shades the rest (each workgroup its own tile).
+  const int n_tiles = tiles_x * tiles_y;
+  static const float share_vertex = getenv("PBR_SKY_SHARE_VERTEX") ? (float)atof(getenv("PBR_SKY_SHARE_VERTEX")) : 0.15f;
+  static const float share_setup = getenv("PBR_SKY_SHARE_SETUP") ? (float)atof(getenv("PBR_SKY_SHARE_SETUP")) : 0.40f;
+  SkyShare sky_a, sky_b;
+  sky_a.sky = pr->sky_b.cube; sky_a.rgba8 = reinterpret_cast<uint32_t*>(color); sky_a.first = 0; sky_a.count = (int)(n_tiles * share_vertex); sky_a.own_blocks = 0;
+  sky_b = sky_a; sky_b.first = sky_a.count; sky_b.count = std::min(n_tiles - sky_a.count, (int)(n_tiles * share_setup));
+  const int sky_from_tile = sky_b.first + sky_b.count;
+  launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances, sky_a);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
   launch_setup_and_bin(s, dp, c->d_vout, c->d_indices, c->d_setup, c->d_records, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
-                       (uint32_t)c->overflow_cap, c->d_counters, c->n_indices / 3, c->n_instances);
+                       (uint32_t)c->overflow_cap, c->d_counters, c->n_indices / 3, c->n_instances, sky_b);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   // the specialised resolve covers the reference's default sampler on power-of-two textures
   static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
@@ -291,7 +302,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // coverage count of the statistics, or the general-sampler resolve
   const bool write_vis = d_vis != nullptr || want_host_vis || timed || !fast;
   launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
-                c->d_counters, c->quad_lists, write_vis, pr->sky_b.cube, color, tiles_x, tiles_y);
+                c->d_counters, c->quad_lists, write_vis, pr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
 
   ResolveInputs in;
@@ -730,7 +741,8 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   mat4_mul_host(u->projection, u->view, fp.pv);
   fp.W = 32; fp.H = 32; fp.y0 = 0; fp.y1 = 32; fp.tiles_x = 1; fp.tiles_y = 1;
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances; fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
-  launch_vertex_stage(c->stream, fp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances);
+  SkyShare none = {};
+  launch_vertex_stage(c->stream, fp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances, none);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const size_t nv = (size_t)c->n_verts * c->n_instances;
   std::vector<VertexOut> host(nv);

@@ -146,14 +146,15 @@ void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* sam
                       float4* out_level, int level_size, int64_t first, int64_t count);
 void launch_brdf_lut(hipStream_t s, uint16_t* out, int size);
 
+struct SkyShare;   // sky_shade.h
 void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa, const float* inst_model, const float* inst_normal,
-                         VertexOut* out, uint32_t* counters, int n_verts, int n_instances);
+                         VertexOut* out, uint32_t* counters, int n_verts, int n_instances, const SkyShare& share);
 void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
-                          int n_tris, int n_instances);
+                          int n_tris, int n_instances, const SkyShare& share);
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                    uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, const QuadLists& lists, bool write_vis,
-                   const DevCube& sky_bordered, uint8_t* rgba8, int tiles_x, int tiles_y);
+                   const DevCube& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y);
 struct ResolveInputs {
   const TriRecord* records;
   const VertexOut* vout;

@@ -21,12 +21,14 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) vertex_kernel(const FrameParams frame_params, const float* __restrict__ vsoa,
                                                      const float* __restrict__ inst_model, const float* __restrict__ inst_normal,
-                                                     VertexOut* __restrict__ out, uint32_t* __restrict__ counters, int n_verts) {
+                                                     VertexOut* __restrict__ out, uint32_t* __restrict__ counters, int n_verts, int blocks_per_instance,
+                                                     SkyShare share) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
-  const int inst = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.x >= share.own_blocks) { sky_tile(p, share.sky, share.rgba8, share.first + (int)blockIdx.x - share.own_blocks); return; }
+  const int inst = (int)blockIdx.x / blocks_per_instance;
+  const int i = ((int)blockIdx.x - inst * blocks_per_instance) * 256 + threadIdx.x;
   // first kernel of a frame: re-arm the setup-triangle and bin-overflow counters the later kernels append with
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { counters[0] = 0u; counters[1] = 0u; counters[6] = 0u; counters[7] = 0u; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { counters[0] = 0u; counters[1] = 0u; counters[6] = 0u; counters[7] = 0u; }
   if (i >= n_verts) return;
   float model[16], nmat[16], pvm[16];
   const float* msrc = p->has_instance_mats ? inst_model + 16 * inst : p->u.model;
@@ -226,10 +228,12 @@ PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint16
 }
 
 __global__ void __launch_bounds__(256) setup_kernel(const FrameParams frame_params, const VertexOut* __restrict__ vout,
-                                                    const uint16_t* __restrict__ indices, BinTargets bt, int n_tris) {
+                                                    const uint16_t* __restrict__ indices, BinTargets bt, int n_tris, int blocks_per_instance,
+                                                    SkyShare share) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
-  const int inst = blockIdx.y;
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  if ((int)blockIdx.x >= share.own_blocks) { sky_tile(p, share.sky, share.rgba8, share.first + (int)blockIdx.x - share.own_blocks); return; }
+  const int inst = (int)blockIdx.x / blocks_per_instance;
+  const int t = ((int)blockIdx.x - inst * blocks_per_instance) * 256 + threadIdx.x;
   Deferred d;
   d.slot = 0xffffffffu; d.box = 0;
   if (t < n_tris) setup_one(p, vout, indices, bt, inst, t, n_tris, &d);
@@ -273,7 +277,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
                                                      uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
                                                      const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
                                                      float* __restrict__ depth, uint32_t* __restrict__ counters, QuadLists lists, int write_vis, DevCube sky,
-                                                     uint32_t* __restrict__ rgba8) {
+                                                     uint32_t* __restrict__ rgba8, int sky_from_tile) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
   __shared__ uint32_t s_pairs[4], s_base[2];
@@ -420,7 +424,8 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
     }
     // The background pixels of the tile get their final colour here (skybox.wgsl:24-33): most tiles hold no
     // geometry at all, and their workgroups would otherwise have nothing to do.
-    if (!(ids[0] && ids[1] && ids[2] && ids[3])) {
+    // (tiles below sky_from_tile were already filled by the workgroups riding along in the vertex and setup launches)
+    if (tile >= sky_from_tile && !(ids[0] && ids[1] && ids[2] && ids[3])) {
       uint32_t c[4];
       sky_pixels4(p, sky, x, y, c);
       if (wide && !(ids[0] | ids[1] | ids[2] | ids[3])) {
@@ -477,26 +482,31 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
 }  // namespace
 
 void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa, const float* inst_model, const float* inst_normal,
-                         VertexOut* out, uint32_t* counters, int n_verts, int n_instances) {
-  dim3 grid((n_verts + 255) / 256, n_instances);
-  hipLaunchKernelGGL(vertex_kernel, grid, dim3(256), 0, s, p, vsoa, inst_model, inst_normal, out, counters, n_verts);
+                         VertexOut* out, uint32_t* counters, int n_verts, int n_instances, const SkyShare& share_in) {
+  const int per_instance = (n_verts + 255) / 256;
+  SkyShare share = share_in;
+  share.own_blocks = per_instance * n_instances;
+  hipLaunchKernelGGL(vertex_kernel, dim3(share.own_blocks + share.count), dim3(256), 0, s, p, vsoa, inst_model, inst_normal, out, counters, n_verts,
+                     per_instance, share);
 }
 
 void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
-                          int n_tris, int n_instances) {
+                          int n_tris, int n_instances, const SkyShare& share_in) {
   // tile_count is zero on entry (the raster kernel of the previous frame clears it) and the vertex
   // kernel has reset the append counters
   BinTargets bt;
   bt.setup = setup; bt.setup_cap = setup_cap; bt.tile_count = tile_count; bt.bins = bins; bt.overflow = overflow; bt.overflow_cap = overflow_cap;
   bt.counters = counters; bt.records = records;
-  dim3 grid((n_tris + 255) / 256, n_instances);
-  hipLaunchKernelGGL(setup_kernel, grid, dim3(256), 0, s, p, vout, indices, bt, n_tris);
+  const int per_instance = (n_tris + 255) / 256;
+  SkyShare share = share_in;
+  share.own_blocks = per_instance * n_instances;
+  hipLaunchKernelGGL(setup_kernel, dim3(share.own_blocks + share.count), dim3(256), 0, s, p, vout, indices, bt, n_tris, per_instance, share);
 }
 
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                    uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, const QuadLists& lists, bool write_vis,
-                   const DevCube& sky_bordered, uint8_t* rgba8, int tiles_x, int tiles_y) {
+                   const DevCube& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y) {
   hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
-                     lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8));
+                     lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile);
 }

@@ -87,3 +87,26 @@ PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCube& sky, 
 #pragma unroll
   for (int k = 0; k < 4; ++k) out[k] = pack_color(weigh4(tap[k], foot[k].w));
 }
+
+// The skybox pass is cut into the same 32 x 32 pixel tiles as the rasteriser.  A tile can be shaded by
+// any 256-thread workgroup: the geometry kernels of a frame are short and latency-bound, so a share
+// of the tiles rides along in their launches as extra workgroups and fills the otherwise idle chip.
+struct SkyShare {
+  DevCube sky;        // bordered skybox cube
+  uint32_t* rgba8;    // colour target of the row range
+  int first, count;   // tiles [first, first + count) are shaded by the workgroups after the kernel's own
+  int own_blocks;     // number of workgroups that do the kernel's own work
+};
+
+// Every pixel of tile `tile` gets the skybox colour (covered ones are overwritten by the surface pass).
+PBR_DEV void sky_tile(const FrameParams* __restrict__ p, const DevCube& sky, uint32_t* __restrict__ rgba8, int tile) {
+  const int tile_x = tile % p->tiles_x, tile_y = tile / p->tiles_x;
+  const int x = tile_x * PBR_TILE + (threadIdx.x & 7) * 4, y = p->y0 + tile_y * PBR_TILE + (threadIdx.x >> 3);
+  if (x >= p->W || y >= p->y1) return;
+  uint32_t c[4];
+  sky_pixels4(p, sky, x, y, c);
+  const size_t o = (size_t)(y - p->y0) * p->W + x;
+  if (x + 3 < p->W && (o & 3) == 0) { *reinterpret_cast<uint4*>(rgba8 + o) = make_uint4(c[0], c[1], c[2], c[3]); return; }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (x + k < p->W) rgba8[o + k] = c[k];
+}
