@@ -726,11 +726,16 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
 }
 
 // Work list driven: the rasteriser leaves two lists of 2x2 pixel quads that hold geometry, and background
-// pixels never start a wavefront here.  An item is sixteen quads of one list (one wavefront, four
-// lanes per quad); the mixed quads, the costlier ones, come first.  One workgroup per compute unit, as
-// many wavefronts as the unit holds; workgroup b owns items b, b + gridDim.x, ... and its waves claim
-// them one at a time from a counter in LDS, so the waves of a unit finish within one item of each other.
+// pixels never start a wavefront here.  An item is sixteen consecutive quads of one list (one
+// wavefront, four lanes per quad).  One workgroup per compute unit, as many wavefronts as the unit
+// holds.  The lists are in tile order, so a contiguous stretch of a list is a compact piece of the
+// screen and of the textures: workgroups are numbered XCD-major (hardware deals workgroup i to XCD
+// i mod 8) and each takes one contiguous stretch of either list, which keeps a unit's twelve waves
+// on neighbouring quads (L1) and an XCD's units on one eighth of the frame (its private L2).  The
+// waves of a workgroup claim its items one at a time from a counter in LDS, mixed quads (the
+// costlier ones) first, so they finish within one item of each other.
 constexpr int kSurfaceThreads = 768;
+constexpr int kXcds = 8;
 __global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(const FrameParams frame_params, ResolveInputs in,
                                                                                const float* __restrict__ srgb_lut, uint32_t* __restrict__ rgba8,
                                                                                QuadLists lists, const uint32_t* __restrict__ counters) {
@@ -741,21 +746,25 @@ __global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(c
   if (threadIdx.x == 0) s_next = 0u;
   __syncthreads();
   const uint32_t n_uniform = counters[6], n_mixed = counters[7];
-  const uint32_t items_mixed = (n_mixed + 15u) >> 4, items = items_mixed + ((n_uniform + 15u) >> 4);
+  const uint32_t items_mixed = (n_mixed + 15u) >> 4, items_uniform = (n_uniform + 15u) >> 4;
+  // gridDim.x is a multiple of kXcds; v runs over the workgroups XCD by XCD
+  const uint32_t per_xcd = gridDim.x / kXcds, v = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds, nv = gridDim.x;
+  const uint32_t m_begin = (uint32_t)((unsigned long long)items_mixed * v / nv), m_end = (uint32_t)((unsigned long long)items_mixed * (v + 1) / nv);
+  const uint32_t u_begin = (uint32_t)((unsigned long long)items_uniform * v / nv), u_end = (uint32_t)((unsigned long long)items_uniform * (v + 1) / nv);
+  const uint32_t own_mixed = m_end - m_begin, own = own_mixed + (u_end - u_begin);
   const int lane = threadIdx.x & 63;
   for (;;) {
     uint32_t k = 0;
     if (lane == 0) k = atomicAdd(&s_next, 1u);
     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-    const uint32_t item = blockIdx.x + k * gridDim.x;
-    if (item >= items) break;
-    if (item >= items_mixed) {
-      const uint32_t q = (item - items_mixed) * 16u + (uint32_t)(lane >> 2);
+    if (k >= own) break;
+    if (k >= own_mixed) {
+      const uint32_t q = (u_begin + k - own_mixed) * 16u + (uint32_t)(lane >> 2);
       const bool live = q < n_uniform;
       const uint2 e = lists.uniform[live ? q : 0u];
       surface_fast_quad<true>(p, in, s_srgb, rgba8, (int)(e.x & 0xffffu) * 2, p->y0 + (int)(e.x >> 16) * 2, e.y, live);
     } else {
-      const uint32_t q = item * 16u + (uint32_t)(lane >> 2);
+      const uint32_t q = (m_begin + k) * 16u + (uint32_t)(lane >> 2);
       const bool live = q < n_mixed;
       const uint32_t pos = lists.mixed_pos[live ? q : 0u];
       const uint32_t id = reinterpret_cast<const uint32_t*>(lists.mixed_ids)[(live ? q : 0u) * 4u + (uint32_t)(lane & 3)];
@@ -810,8 +819,8 @@ void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in
                     const QuadLists& lists, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks) {
   uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
   if (fast) {
-    // no more workgroups than the chip holds at once, and no more than there can be items
-    const int blocks = std::max(1, std::min(tiles_x * tiles_y * 16, resident_blocks));
+    // as many workgroups as the chip holds at once, a multiple of the XCD count
+    const int blocks = std::max(kXcds, resident_blocks / kXcds * kXcds);
     hipLaunchKernelGGL(resolve_surface_fast_kernel, dim3(blocks), dim3(kSurfaceThreads), 0, s, p, in, srgb_lut, out, lists, counters);
   } else {
     dim3 grid((W + 31) / 32, (rows + 7) / 8);
