@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(256) mip_rgba8_kernel(const uint32_t* __restri
   mip_axis(x, dw, sw, x0, x1, a);
   mip_axis(y, dh, sh, y0, y1, b);
   float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
-  uint32_t t00 = src[(size_t)y0 * sw + x0], t10 = src[(size_t)y0 * sw + x1], t01 = src[(size_t)y1 * sw + x0], t11 = src[(size_t)y1 * sw + x1];
+  uint32_t t00 = src[tex8_block_offset(x0, y0, sw)], t10 = src[tex8_block_offset(x1, y0, sw)], t01 = src[tex8_block_offset(x0, y1, sw)],
+           t11 = src[tex8_block_offset(x1, y1, sw)];
   uint32_t out = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -87,7 +88,14 @@ __global__ void __launch_bounds__(256) mip_rgba8_kernel(const uint32_t* __restri
     if (enc) v = linear_to_srgb(v);
     out |= to_unorm8(v) << (8 * c);
   }
-  dst[(size_t)y * dw + x] = out;
+  dst[tex8_block_offset(x, y, dw)] = out;
+}
+
+// Row-major image -> the blocked layout of a texture level.
+__global__ void __launch_bounds__(256) block_rgba8_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int w, int h) {
+  int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  dst[tex8_block_offset(x, y, w)] = src[(size_t)y * w + x];
 }
 
 __global__ void __launch_bounds__(256) equirect_to_cube_kernel(DevEquirect hdr, float4* __restrict__ out, int size) {
@@ -228,7 +236,8 @@ void launch_build_mips_rgba32f(hipStream_t s, float4* chain, const uint32_t* off
   }
 }
 
-void launch_build_mips_rgba8(hipStream_t s, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb) {
+void launch_build_mips_rgba8(hipStream_t s, const uint32_t* linear_level0, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb) {
+  hipLaunchKernelGGL(block_rgba8_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, linear_level0, chain + off[0], w, h);
   for (int l = 1; l < levels; ++l) {
     int sw = std::max(1, w >> (l - 1)), sh = std::max(1, h >> (l - 1)), dw = std::max(1, w >> l), dh = std::max(1, h >> l);
     dim3 grid((dw + 63) / 64, (dh + 3) / 4);

@@ -48,6 +48,14 @@ void chain_offsets(int w, int h, int levels, uint32_t* off, size_t* total) {
   }
   *total = o;
 }
+void tex8_offsets(int w, int h, int levels, uint32_t* off, size_t* total) {
+  size_t o = 0;
+  for (int l = 0; l < PBR_MAX_LEVELS; ++l) {
+    off[l] = (uint32_t)o;
+    if (l < levels) o += tex8_level_texels(std::max(1, w >> l), std::max(1, h >> l));
+  }
+  *total = o;
+}
 void cube_offsets(int size, int levels, uint32_t* off, size_t* total) {
   size_t o = 0;
   for (int l = 0; l < PBR_MAX_LEVELS; ++l) {
@@ -472,12 +480,16 @@ int pbr_upload_texture(PbrContext* c, int slot, const uint8_t* rgba8, int32_t w,
   t.levels = gen_mips ? level_count(w, h) : 1;
   if (t.levels > PBR_MAX_LEVELS) return fail(c, PBR_E_ARG, "too many mip levels");
   size_t total;
-  chain_offsets(w, h, t.levels, t.off, &total);
+  tex8_offsets(w, h, t.levels, t.off, &total);
   HIP_TRY(c, hipMalloc(&c->d_tex[slot], total * sizeof(uint32_t)));
   t.base = c->d_tex[slot];
-  HIP_TRY(c, hipMemcpyAsync(c->d_tex[slot], rgba8, (size_t)w * h * 4, hipMemcpyHostToDevice, c->stream));
-  if (t.levels > 1) launch_build_mips_rgba8(c->stream, c->d_tex[slot], t.off, w, h, t.levels, t.srgb);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  uint32_t* staging = nullptr;   // the row-major image, re-laid into blocks on the device
+  HIP_TRY(c, hipMalloc(&staging, (size_t)w * h * 4));
+  hipError_t up = hipMemcpyAsync(staging, rgba8, (size_t)w * h * 4, hipMemcpyHostToDevice, c->stream);
+  if (up == hipSuccess) launch_build_mips_rgba8(c->stream, staging, c->d_tex[slot], t.off, w, h, t.levels, t.srgb);
+  if (up == hipSuccess) up = hipStreamSynchronize(c->stream);
+  (void)hipFree(staging);
+  HIP_TRY(c, up);
   HIP_TRY(c, hipGetLastError());
   c->tex_has_mips[slot] = t.levels > 1;
   return PBR_OK;

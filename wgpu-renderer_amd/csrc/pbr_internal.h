@@ -13,12 +13,21 @@
 #define PBR_PREFILTER_SAMPLES 1024
 #define PBR_BIN_CAP 256           // triangle references a tile keeps in its own row before spilling to the overflow list
 
-// An rgba8 texture with its mip chain in one allocation.
+// An rgba8 texture with its mip chain in one allocation.  Every level is stored in blocks of 8 x 4
+// texels (128 bytes, one cache line), blocks row by row: a bilinear footprint, and the footprints of
+// neighbouring pixels, then fall into few lines whichever way the texture is oriented on screen.
 struct DevTex8 {
   const uint32_t* base;           // packed r | g<<8 | b<<16 | a<<24
-  uint32_t off[PBR_MAX_LEVELS];   // texel offset of each level
+  uint32_t off[PBR_MAX_LEVELS];   // texel offset of each level (levels are padded to whole blocks)
   int32_t w, h, levels, srgb;
 };
+
+// Offset of texel (x, y) inside a level that is w texels wide.
+__host__ __device__ inline uint32_t tex8_block_offset(int x, int y, int w) {
+  const uint32_t blocks_x = (uint32_t)(w + 7) >> 3;
+  return (((uint32_t)y >> 2) * blocks_x + ((uint32_t)x >> 3)) * 32u + (((uint32_t)y & 3u) << 3) + ((uint32_t)x & 7u);
+}
+__host__ __device__ inline size_t tex8_level_texels(int w, int h) { return (size_t)((w + 7) >> 3) * (size_t)((h + 3) >> 2) * 32u; }
 
 // A cube map (or its mip chain) of rgba32f texels: level l is [6][size>>l][size>>l].
 struct DevCube {
@@ -139,7 +148,8 @@ struct PbrContext {
 
 // ---- kernel launchers (defined in the .hip files) ----
 void launch_build_mips_rgba32f(hipStream_t s, float4* chain, const uint32_t* off, int w, int h, int levels);
-void launch_build_mips_rgba8(hipStream_t s, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb);
+// level 0 from a row-major image, then the box-filtered levels; chain is in the blocked layout of DevTex8
+void launch_build_mips_rgba8(hipStream_t s, const uint32_t* linear_level0, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb);
 void launch_equirect_to_cube(hipStream_t s, DevEquirect hdr, float4* out, int size);
 void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int n_phi, int n_theta, float4* out, int size);
 void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, float inv_weight,

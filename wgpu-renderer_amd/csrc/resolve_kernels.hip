@@ -70,15 +70,14 @@ PBR_DEV float4 sample_2d(const DevTex8& t, Lod2D lod, uint32_t sampler, float u,
   const uint32_t* base = t.base + t.off[lod.level];
   if (!lod.linear) {
     const int x = wrap_coord((int)floorf(u * (float)lw), lw, rep_u), y = wrap_coord((int)floorf(v * (float)lh), lh, rep_v);
-    return decode8(base[(uint32_t)y * lw + x], t.srgb, s_srgb);
+    return decode8(base[tex8_block_offset(x, y, lw)], t.srgb, s_srgb);
   }
   const float tu = u * (float)lw - 0.5f, tv = v * (float)lh - 0.5f;
   const float fu = floorf(tu), fv = floorf(tv);
   const int x0 = wrap_coord((int)fu, lw, rep_u), x1 = wrap_coord((int)fu + 1, lw, rep_u);
   const int y0 = wrap_coord((int)fv, lh, rep_v), y1 = wrap_coord((int)fv + 1, lh, rep_v);
-  const uint32_t r0 = (uint32_t)y0 * lw, r1 = (uint32_t)y1 * lw;
-  return bilerp4(decode8(base[r0 + x0], t.srgb, s_srgb), decode8(base[r0 + x1], t.srgb, s_srgb), decode8(base[r1 + x0], t.srgb, s_srgb),
-                 decode8(base[r1 + x1], t.srgb, s_srgb), tu - fu, tv - fv);
+  return bilerp4(decode8(base[tex8_block_offset(x0, y0, lw)], t.srgb, s_srgb), decode8(base[tex8_block_offset(x1, y0, lw)], t.srgb, s_srgb),
+                 decode8(base[tex8_block_offset(x0, y1, lw)], t.srgb, s_srgb), decode8(base[tex8_block_offset(x1, y1, lw)], t.srgb, s_srgb), tu - fu, tv - fv);
 }
 
 // rgba16f split-sum table sampled with the material sampler (shader.wgsl:150): one level, so the
@@ -297,8 +296,11 @@ PBR_DEV Footprint footprint_fast(const DevTex8& t, int level, float u, float v) 
   const float tu = u * (float)lw - 0.5f, tv = v * (float)lh - 0.5f;
   const float fu = floorf(tu), fv = floorf(tv), a = tu - fu, b = tv - fv;
   const int x0 = (int)fu & (lw - 1), x1 = ((int)fu + 1) & (lw - 1), y0 = (int)fv & (lh - 1), y1 = ((int)fv + 1) & (lh - 1);
-  const uint32_t base = t.off[level], r0 = base + (uint32_t)y0 * lw, r1 = base + (uint32_t)y1 * lw;
-  f.o00 = r0 + x0; f.o10 = r0 + x1; f.o01 = r1 + x0; f.o11 = r1 + x1;
+  // blocked layout (see DevTex8): block row and in-block row of each of the two rows, block column and in-block column of each of the two columns
+  const uint32_t base = t.off[level], blocks_x = (uint32_t)(lw + 7) >> 3;
+  const uint32_t r0 = base + ((uint32_t)y0 >> 2) * blocks_x * 32u + (((uint32_t)y0 & 3u) << 3), r1 = base + ((uint32_t)y1 >> 2) * blocks_x * 32u + (((uint32_t)y1 & 3u) << 3);
+  const uint32_t c0 = ((uint32_t)x0 >> 3) * 32u + ((uint32_t)x0 & 7u), c1 = ((uint32_t)x1 >> 3) * 32u + ((uint32_t)x1 & 7u);
+  f.o00 = r0 + c0; f.o10 = r0 + c1; f.o01 = r1 + c0; f.o11 = r1 + c1;
   f.w00 = (1.0f - a) * (1.0f - b); f.w10 = a * (1.0f - b); f.w01 = (1.0f - a) * b; f.w11 = a * b;
   return f;
 }
