@@ -23,6 +23,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")   # PMC pass of scripts/gpu_traffic.sh over this same workload
+
+
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed counter measurement (the benchmark
+    itself runs without a profiler); None if there is none."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            return float(json.load(f)[kernel]["hbm_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def parse_args():
@@ -179,7 +190,7 @@ def main():
                        "covered_fraction": c, "triangles": tri_sum // max(n_cov, 1), "parallelism": "replicas only" if world == 1 else f"frame-sharded x{world}"},
             "kernel_ms": {"resolve_surface_fast_kernel": surf_ms, "gpu_frame": frame_ms},
             "roofline": {"bound": "hbm", "kernel": "resolve_surface_fast_kernel", "achieved": surf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": surf_gbs / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": surf_bytes},
+                         "frac": surf_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("resolve_surface_fast_kernel"), "algorithmic_bytes": surf_bytes},
             "frame_roofline": {"bound": "hbm", "kernels": "all kernels of one frame (vertex, setup, raster+sky, surface), end of one frame to end of the next", "achieved": frame_gbs,
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS, "algorithmic_bytes": frame_bytes},
         }

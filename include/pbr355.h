@@ -120,7 +120,9 @@ int pbr_ibl_level_info(PbrContext* ctx, int which, int32_t level, int32_t* w, in
 /* Copy one level to host memory (rgba32f, or rgba16f bits for the LUT). */
 int pbr_ibl_download(PbrContext* ctx, int which, int32_t level, void* out, size_t out_bytes);
 /* Device address of a whole map (all levels back to back) for device-side exchange, e.g. an
- * all-gather of prefilter shards; total_bytes may be NULL. */
+ * all-gather of prefilter shards; total_bytes may be NULL.  The library samples cube maps through
+ * a derived copy that it rebuilds at the first frame after this call: call it (again) after the
+ * last write through the pointer, and order that write before the frame. */
 int pbr_ibl_device_ptr(PbrContext* ctx, int which, void** dev_ptr, size_t* total_bytes);
 /* Byte range [begin,end) of the prefilter map that shard (shard_index, shard_count) writes. */
 int pbr_ibl_prefilter_shard_range(PbrContext* ctx, int32_t shard_index, int32_t shard_count, size_t* begin, size_t* end);

@@ -35,6 +35,11 @@ def prefilter_sharded(renderer, size, mips, rank=None, world=None, device=None):
     whole = device_bytes_tensor(ptr.value, total.value, device)
     renderer.synchronize()
     all_gather_ranges(whole, [tuple(16 * t for t in sharding.prefilter_shard_texels(size, mips, r, world)) for r in range(world)], rank)
+    # the gather ran on torch's stream and wrote through the library's pointer: finish it before the
+    # renderer's stream reads the map (the library rebuilds its derived copy at the next frame, which
+    # the pbr_ibl_device_ptr call above has requested)
+    if whole.is_cuda:
+        torch.cuda.current_stream(whole.device).synchronize()
 
 
 def all_gather_ranges(whole, byte_ranges, rank):
