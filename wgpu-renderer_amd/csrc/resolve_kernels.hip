@@ -736,7 +736,10 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
 // on neighbouring quads (L1) and an XCD's units on one eighth of the frame (its private L2).  The
 // waves of a workgroup claim its items one at a time from a counter in LDS, mixed quads (the
 // costlier ones) first, so they finish within one item of each other.
-constexpr int kSurfaceThreads = 768;
+#ifndef PBR_SURFACE_THREADS
+#define PBR_SURFACE_THREADS 768
+#endif
+constexpr int kSurfaceThreads = PBR_SURFACE_THREADS;
 constexpr int kXcds = 8;
 __global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(const FrameParams frame_params, ResolveInputs in,
                                                                                const float* __restrict__ srgb_lut, uint32_t* __restrict__ rgba8,

@@ -60,26 +60,56 @@ PBR_DEV V3 weigh4(const float4 t[4], const float w[4]) {
 }
 
 
+// Face coordinates (sc, tc, rc) of direction d on a given face: the rows of the face-selection table.
+PBR_DEV void cube_face_coords(int face, V3 d, float& sc, float& tc, float& rc) {
+  switch (face) {
+    case 0: sc = -d.z; tc = -d.y; rc = d.x; break;
+    case 1: sc = d.z;  tc = -d.y; rc = d.x; break;
+    case 2: sc = d.x;  tc = d.z;  rc = d.y; break;
+    case 3: sc = d.x;  tc = -d.z; rc = d.y; break;
+    case 4: sc = d.x;  tc = -d.y; rc = d.z; break;
+    default: sc = -d.x; tc = -d.y; rc = d.z; break;
+  }
+}
+
 // Skybox colour of four horizontally adjacent pixels (x0 .. x0+3, y): the clip-space position is
 // unprojected with the inverse view-projection matrix and the bordered cube sampled bilinearly; all
-// sixteen taps are issued before any is used.
+// sixteen taps are issued before any is used.  The unprojected direction is affine in x, so the
+// cube face is selected once, for the first pixel, and the face coordinates of the other three are
+// that pixel's plus a constant step; a pixel that has left the face (its major axis is no longer
+// the largest component, or w has changed sign) takes the full selection again.
 PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCube& sky, int x0, int y, uint32_t out[4]) {
 #pragma clang fp contract(fast)
   const float* m = p->u.inv_view_proj;
   const float two_over_w = 2.0f / (float)p->W;
   const float yn = 1.0f - ((float)y + 0.5f) * (2.0f / (float)p->H);
+  const float xn = ((float)x0 + 0.5f) * two_over_w - 1.0f;
+  // normalize(xyz / w) only rescales the lookup direction by 1 / (w |xyz|); the cube lookup depends on
+  // the direction alone, so only the sign of w is applied.
+  const float tx = ((m[0] * xn + m[4] * yn) + m[8]) + m[12], ty = ((m[1] * xn + m[5] * yn) + m[9]) + m[13];
+  const float tz = ((m[2] * xn + m[6] * yn) + m[10]) + m[14], tw = ((m[3] * xn + m[7] * yn) + m[11]) + m[15];
+  const float sg = tw < 0.0f ? -1.0f : 1.0f;
+  const V3 d0 = v3(tx * sg, ty * sg, -(tz * sg));
+  const V3 step = v3(m[0] * two_over_w * sg, m[1] * two_over_w * sg, -(m[2] * two_over_w * sg));
+  const float w_step = m[3] * two_over_w;
+  const CubeCoord first = cube_select(d0);
+  float dsc, dtc, drc;
+  cube_face_coords(first.face, step, dsc, dtc, drc);
   CubeFoot foot[4];
+  foot[0] = cube_foot(sky, 0, first);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float xn = ((float)(x0 + k) + 0.5f) * two_over_w - 1.0f;
-    const float tx = ((m[0] * xn + m[4] * yn) + m[8]) + m[12];
-    const float ty = ((m[1] * xn + m[5] * yn) + m[9]) + m[13];
-    const float tz = ((m[2] * xn + m[6] * yn) + m[10]) + m[14];
-    const float tw = ((m[3] * xn + m[7] * yn) + m[11]) + m[15];
-    // normalize(xyz / w) only rescales the lookup direction by 1 / (w |xyz|); the cube lookup depends on
-    // the direction alone, so only the sign of w is applied.
-    const float sg = tw < 0.0f ? -1.0f : 1.0f;
-    foot[k] = cube_foot(sky, 0, cube_select(v3(tx * sg, ty * sg, -(tz * sg))));
+  for (int k = 1; k < 4; ++k) {
+    CubeCoord c;
+    c.face = first.face;
+    c.sc = first.sc + (float)k * dsc; c.tc = first.tc + (float)k * dtc; c.rc = first.rc + (float)k * drc;
+    const float wk = tw + (float)k * w_step;
+    const bool same_face = fabsf(c.rc) >= fabsf(c.sc) && fabsf(c.rc) >= fabsf(c.tc) && (c.rc < 0.0f) == (first.rc < 0.0f) && (wk < 0.0f) == (tw < 0.0f);
+    if (!same_face) {
+      const float sk = wk < 0.0f ? -1.0f : 1.0f, xk = xn + (float)k * two_over_w;
+      const float ax = ((m[0] * xk + m[4] * yn) + m[8]) + m[12], ay = ((m[1] * xk + m[5] * yn) + m[9]) + m[13], az = ((m[2] * xk + m[6] * yn) + m[10]) + m[14];
+      c = cube_select(v3(ax * sk, ay * sk, -(az * sk)));
+    }
+    foot[k] = cube_foot(sky, 0, c);
   }
   float4 tap[4][4];
 #pragma unroll
