@@ -106,19 +106,21 @@ class SmallScene:
 
     @classmethod
     def build(cls, width=320, height=180, hdr_size=(2048, 1024), sky_size=64, pre_size=32, pre_mips=4, lut_size=64, irr_size=8,
-              gpu=True, instance_models=None, seed=355):
+              gpu=True, instance_models=None, seed=355, model_path=None, reference_limits=True):
         pkg = _pkg()
         self = cls()
         self.pkg = pkg
         hdr = pkg.synthetic_sky(hdr_size[0], hdr_size[1], seed)
         self.hdr = hdr
         r = pkg.Renderer(width=width, height=height, hdr=hdr, skybox_size=sky_size, irradiance_size=irr_size, prefilter_size=pre_size,
-                         prefilter_mips=pre_mips, lut_size=lut_size, instance_models=instance_models)
+                         prefilter_mips=pre_mips, lut_size=lut_size, instance_models=instance_models, reference_limits=reference_limits,
+                         **({"model_path": model_path} if model_path else {}))
         r.load_model()
         self.renderer = r
         g = r.geometries[0]
         t = g.textures
-        images = [pkg.load_image_bitmap(t[k]) for k in ("baseColorURI", "metallicRoughnessURI", "normalURI", "emissiveURI", "occlusionURI")]
+        keys = ("baseColorURI", "metallicRoughnessURI", "normalURI", "emissiveURI", "occlusionURI")
+        images = [pkg.load_image_bitmap(t[k]) if t[k] is not None else np.array([[pkg.gltf.DEFAULT_TEXEL[k]]], dtype=np.uint8) for k in keys]
         normals = None
         if instance_models is not None:
             normals = np.stack([pkg.mathx.transpose(pkg.mathx.inverse(m)) for m in np.asarray(instance_models, dtype=np.float32).reshape(-1, 16)])

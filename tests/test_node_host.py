@@ -39,8 +39,28 @@ def small_hdr(tmp_path_factory, pkg):
 
 
 @pytest.fixture(scope="module")
-def js_dump(small_hdr):
-    proc = subprocess.run(["node", os.path.join(HOST, "test", "dump_host.js"), MODEL, small_hdr, ALBEDO], stdout=subprocess.PIPE,
+def older_hdrs(tmp_path_factory, pkg):
+    """The same image in the two pre-RLE scanline encodings (with a run of equal pixels in it)."""
+    sky = pkg.hdr.synthetic_sky(64, 32, seed=3).data.reshape(32, 64, 4)[..., :3].copy()
+    sky[5, 10:40] = sky[5, 10]
+    sky[6, :] = sky[6, 0]
+    d = tmp_path_factory.mktemp("hdr_old")
+    paths = (str(d / "flat.hdr"), str(d / "old_rle.hdr"), str(d / "new_rle.hdr"))
+    pkg.hdr.write_hdr_flat(paths[0], sky)
+    pkg.hdr.write_hdr_flat(paths[1], sky, old_rle=True)
+    pkg.hdr.write_hdr_rle(paths[2], sky)
+    return paths
+
+
+@pytest.fixture(scope="module")
+def general_gltf(tmp_path_factory):
+    import gltf_samples
+    return gltf_samples.write_interleaved_quad(str(tmp_path_factory.mktemp("gltf")))[0]
+
+
+@pytest.fixture(scope="module")
+def js_dump(small_hdr, older_hdrs, general_gltf):
+    proc = subprocess.run(["node", os.path.join(HOST, "test", "dump_host.js"), MODEL, small_hdr, ALBEDO, older_hdrs[0], older_hdrs[1], general_gltf], stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, text=True, timeout=120)
     assert proc.returncode == 0, proc.stderr
     return json.loads(proc.stdout)
@@ -64,11 +84,47 @@ def test_gltf_loader_matches(js_dump, pkg):
 
 
 @needs_node
+def test_general_gltf_loader_matches(js_dump, general_gltf, pkg):
+    loader = pkg.glTFLoader(reference_limits=False)
+    loader.load(general_gltf)
+    g = loader.get_geometries()[0]
+    j = js_dump["generalGeometry"]
+    assert j["vertices"] == _sha(g.vertices.astype(np.float32)) and j["indices"] == _sha(g.indices.astype(np.uint16))
+    assert j["model"] == _hex(np.asarray(g.model, dtype=np.float32))
+    assert all(j["textures"][k] is None for k in ("baseColorURI", "metallicRoughnessURI", "normalURI", "emissiveURI", "occlusionURI"))
+    assert j["textures"]["emissive"] == [0, 0, 0]
+
+
+@needs_node
 def test_hdr_loader_matches(js_dump, small_hdr, pkg):
     loader = pkg.HDRLoader()
     loader.load(small_hdr)
     assert (js_dump["hdr"]["width"], js_dump["hdr"]["height"]) == (64, 32)
     assert js_dump["hdr"]["data"] == _sha(loader.hdr.data.astype(np.float32))
+
+
+def test_hdr_older_encodings_python(older_hdrs, pkg):
+    """Flat and old-RLE scanlines decode to the same pixels as the new-RLE file of the same image; the
+    default loader keeps the reference's refusal."""
+    ref = pkg.HDRLoader()
+    ref.load(older_hdrs[2])
+    assert os.path.getsize(older_hdrs[1]) < os.path.getsize(older_hdrs[0])     # the runs were really encoded
+    for path in older_hdrs[:2]:
+        loader = pkg.HDRLoader(reference_limits=False)
+        loader.load(path)
+        assert (loader.width, loader.height) == (64, 32)
+        assert np.array_equal(loader.hdr.data, ref.hdr.data)
+        with pytest.raises(RuntimeError, match="Only support RLE format"):     # hdr.ts:81
+            pkg.HDRLoader().load(path)
+
+
+@needs_node
+def test_hdr_older_encodings_js(js_dump, older_hdrs, pkg):
+    ref = pkg.HDRLoader()
+    ref.load(older_hdrs[2])
+    for got in js_dump["hdrOlder"]:
+        assert (got["width"], got["height"]) == (64, 32)
+        assert got["data"] == _sha(ref.hdr.data.astype(np.float32))
 
 
 @needs_node

@@ -1,7 +1,12 @@
 """glTF loader with the reference's surface (src/glTF.ts): `glTFLoader().load(path)` then
 `get_geometries()`.  `url` is a filesystem path.  Behaviour follows the reference, including its
 limits: one buffer view per attribute read from its start, a fixed 8-float vertex, uint16 indices,
-the last primitive of a node wins, and node matrix = I * scale * translate * rotation."""
+the last primitive of a node wins, and node matrix = I * scale * translate * rotation.
+
+`glTFLoader(reference_limits=False)` reads accessors the way the glTF 2.0 specification defines
+them instead (accessor.byteOffset, bufferView.byteStride, 8/16/32-bit indices as long as the
+vertex count fits 16-bit indices) and tolerates a material without some of the five textures
+(the missing URI is None and the renderer substitutes a neutral 1x1 texture)."""
 import json
 import os
 from dataclasses import dataclass, field
@@ -44,8 +49,18 @@ class Geometry:
     textures: dict = field(default_factory=dict)
 
 
+_NP_TYPE = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_COMPONENTS = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT2": 4, "MAT3": 9, "MAT4": 16}
+
+# neutral stand-ins for material textures a file does not have (RGBA8): white base colour, roughness 1 /
+# metalness 1 (scaled by nothing in the reference shader), flat normal, black emissive, no occlusion
+DEFAULT_TEXEL = {"baseColorURI": (255, 255, 255, 255), "metallicRoughnessURI": (255, 255, 255, 255), "normalURI": (128, 128, 255, 255),
+                 "emissiveURI": (0, 0, 0, 255), "occlusionURI": (255, 255, 255, 255)}
+
+
 class glTFLoader:  # noqa: N801 - the reference's class name
-    def __init__(self):
+    def __init__(self, reference_limits=True):
+        self.reference_limits = reference_limits
         self.pathname = ""
         self.gltf = None
         self.buffers = []
@@ -86,6 +101,50 @@ class glTFLoader:  # noqa: N801 - the reference's class name
         return np.frombuffer(self.buffers[view["buffer"]], dtype=np.float32, count=view["byteLength"] // 4,
                              offset=view.get("byteOffset", 0))
 
+    def _accessor(self, index):
+        """Accessor data as the glTF 2.0 specification lays it out: [count, components]."""
+        acc = self.gltf["accessors"][index]
+        view = self.gltf["bufferViews"][acc["bufferView"]]
+        dtype = np.dtype(_NP_TYPE[acc["componentType"]])
+        comps = _COMPONENTS[acc["type"]]
+        start = view.get("byteOffset", 0) + acc.get("byteOffset", 0)
+        stride = view.get("byteStride", 0) or dtype.itemsize * comps
+        raw = np.frombuffer(self.buffers[view["buffer"]], dtype=np.uint8)
+        count = acc["count"]
+        if start + (count - 1) * stride + dtype.itemsize * comps > raw.size:
+            raise RuntimeError("Accessor reaches past the end of its buffer.")
+        rows = np.lib.stride_tricks.as_strided(raw[start:], shape=(count, dtype.itemsize * comps), strides=(stride, 1))
+        return np.ascontiguousarray(rows).view(dtype).reshape(count, comps)
+
+    def _general_primitive(self, primitive):
+        g = self.gltf
+        pos = self._accessor(primitive["attributes"]["POSITION"]).astype(np.float32)
+        count = pos.shape[0]
+        attrs = primitive["attributes"]
+        uv = self._accessor(attrs["TEXCOORD_0"]).astype(np.float32) if "TEXCOORD_0" in attrs else np.zeros((count, 2), np.float32)
+        nrm = self._accessor(attrs["NORMAL"]).astype(np.float32) if "NORMAL" in attrs else np.tile(np.float32([0, 0, 1]), (count, 1))
+        if count > 65536:
+            raise RuntimeError("More than 65536 vertices in one primitive: the draw path indexes with 16 bits.")
+        vertices = np.concatenate([pos[:, :3], uv[:, :2], nrm[:, :3]], axis=1).astype(np.float32).reshape(-1)
+        if "indices" in primitive:
+            indices = self._accessor(primitive["indices"]).reshape(-1).astype(np.uint16)
+        else:
+            indices = np.arange(count, dtype=np.uint16)
+        material = g.get("materials", [{}])[primitive.get("material", 0)] if g.get("materials") else {}
+        pbr = material.get("pbrMetallicRoughness", {})
+
+        def uri(slot):
+            if slot is None or "index" not in slot:
+                return None
+            return self.pathname + g["images"][g["textures"][slot["index"]]["source"]]["uri"]
+
+        textures = {
+            "baseColorURI": uri(pbr.get("baseColorTexture")), "metallicRoughnessURI": uri(pbr.get("metallicRoughnessTexture")),
+            "normalURI": uri(material.get("normalTexture")), "emissive": list(material.get("emissiveFactor", [0.0, 0.0, 0.0])),
+            "emissiveURI": uri(material.get("emissiveTexture")), "occlusionURI": uri(material.get("occlusionTexture")),
+        }
+        return vertices, indices, textures
+
     def _generate_geometries(self):
         g = self.gltf
         nodes = g["nodes"]
@@ -105,6 +164,12 @@ class glTFLoader:  # noqa: N801 - the reference's class name
             mesh = g["meshes"][node["mesh"]]
             for primitive in mesh["primitives"]:
                 if "mode" in primitive and primitive["mode"] != 4:                    # glTF.ts:134-136
+                    continue
+                if not self.reference_limits:
+                    vertices, indices, textures = self._general_primitive(primitive)
+                    self.geometries[index] = Geometry(model=model, vertices=vertices, array_stride=32, position=Layout("float32x3", 0),
+                                                      tex_coord=Layout("float32x2", 12), normal=Layout("float32x3", 20), indices=indices,
+                                                      textures=textures)
                     continue
                 pos_acc = g["accessors"][primitive["attributes"]["POSITION"]]
                 uv_acc = g["accessors"][primitive["attributes"]["TEXCOORD_0"]]

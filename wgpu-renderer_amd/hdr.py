@@ -16,7 +16,13 @@ class HDR:
 
 
 class HDRLoader:
-    def __init__(self):
+    """`reference_limits=True` (default) keeps the reference's parser exactly, errors included: only
+    new-style RLE scanlines.  With False the loader also reads the two older scanline encodings of
+    the Radiance format (flat RGBE pixels, and runs marked by a (1,1,1,n) pixel), which the
+    reference rejects with "Only support RLE format."."""
+
+    def __init__(self, reference_limits=True):
+        self.reference_limits = reference_limits
         self.buffer = b""
         self.width = 0
         self.height = 0
@@ -36,6 +42,10 @@ class HDRLoader:
     def load_bytes(self, data):
         self.buffer = bytes(data)
         self._parse_hdr()
+
+    @staticmethod
+    def _old_scanline(raw, index, out_row):
+        return _old_scanline_impl(raw, index, out_row)
 
     def _parse_hdr(self):
         b = self.buffer
@@ -61,9 +71,16 @@ class HDRLoader:
         row = 0
         while index < n:
             head = raw[index:index + 4]
+            new_rle = len(head) == 4 and head[0] == 2 and head[1] == 2 and (int(head[2]) << 8) + int(head[3]) == w
+            if not new_rle:
+                if self.reference_limits:
+                    raise RuntimeError("HDRLoader: Only support RLE format.")     # hdr.ts:81
+                if row >= h:
+                    break
+                index = self._old_scanline(raw, index, scan[row])
+                row += 1
+                continue
             index += 4
-            if len(head) < 4 or head[0] != 2 or head[1] != 2 or (int(head[2]) << 8) + int(head[3]) != w:
-                raise RuntimeError("HDRLoader: Only support RLE format.")         # hdr.ts:81
             for c in range(4):
                 pos = 0
                 while pos < w:
@@ -87,6 +104,37 @@ class HDRLoader:
         out[..., :3] = (scan[..., :3].astype(np.float64) * scale[..., None]).astype(np.float32)
         out[..., 3] = 1.0
         self.data = out.reshape(-1)
+
+
+def _old_scanline_impl(raw, index, out_row):
+    """One scanline in the pre-1991 encodings: RGBE pixels one after the other; a pixel (1,1,1,n) repeats
+    the previous pixel n times, consecutive such pixels shifting their counts by 8 bits each."""
+    w = out_row.shape[0]
+    n = len(raw)
+    # fast path: a flat scanline with no run markers
+    if index + 4 * w <= n:
+        px = raw[index:index + 4 * w].reshape(w, 4)
+        if not ((px[:, 0] == 1) & (px[:, 1] == 1) & (px[:, 2] == 1)).any():
+            out_row[:] = px
+            return index + 4 * w
+    pos, shift = 0, 0
+    while pos < w:
+        if index + 4 > n:
+            raise RuntimeError("HDRLoader: Unexpected end of file.")
+        r, g, b, e = (int(v) for v in raw[index:index + 4])
+        index += 4
+        if r == 1 and g == 1 and b == 1:
+            count = e << shift
+            if pos == 0 or pos + count > w:
+                raise RuntimeError("HDRLoader: Bad scanline data.")
+            out_row[pos:pos + count] = out_row[pos - 1]
+            pos += count
+            shift += 8
+        else:
+            out_row[pos] = (r, g, b, e)
+            pos += 1
+            shift = 0
+    return index
 
 
 def float_to_rgbe(rgb):
@@ -117,6 +165,32 @@ def write_hdr_rle(path_or_none, rgb):
             for s in range(0, w, 128):
                 chunk = ch[s:s + 128]
                 parts.append(bytes([len(chunk)]) + chunk)
+    data = b"".join(parts)
+    if path_or_none:
+        with open(path_or_none, "wb") as f:
+            f.write(data)
+    return data
+
+
+def write_hdr_flat(path_or_none, rgb, old_rle=False):
+    """Encode [h, w, 3] floats as flat RGBE scanlines; with old_rle, repeated pixels become (1,1,1,n) runs."""
+    h, w, _ = rgb.shape
+    rgbe = float_to_rgbe(rgb)
+    parts = [b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (h, w)]
+    for y in range(h):
+        row = rgbe[y]
+        if not old_rle:
+            parts.append(row.tobytes())
+            continue
+        x = 0
+        while x < w:
+            run = 1
+            while x + run < w and run < 255 and (row[x + run] == row[x]).all():
+                run += 1
+            parts.append(row[x].tobytes())
+            if run > 1:
+                parts.append(bytes([1, 1, 1, run - 1]))
+            x += run
     data = b"".join(parts)
     if path_or_none:
         with open(path_or_none, "wb") as f:

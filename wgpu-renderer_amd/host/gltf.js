@@ -3,6 +3,10 @@
 // `await load(url)`, `getGeometries()`.  `url` is a filesystem path.  Like the reference it reads
 // whole bufferViews (accessor offsets and strides are ignored), expects float32 POSITION /
 // TEXCOORD_0 / NORMAL and uint16 indices, and takes every material texture without guards.
+// `new glTFLoader({ referenceLimits: false })` reads accessors as the glTF 2.0 specification defines
+// them instead (accessor.byteOffset, bufferView.byteStride, 8/16/32-bit indices while the vertex
+// count fits 16-bit indices) and tolerates missing material textures (URI null; the renderer
+// substitutes a neutral 1x1 texture).
 const fs = require('fs');
 const { mat4 } = require('./mat.js');
 const { calculateByteLength } = require('./utils.js');
@@ -10,8 +14,15 @@ const { calculateByteLength } = require('./utils.js');
 const ComponentType = { 5120: 'sint8', 5121: 'uint8', 5122: 'sint16', 5123: 'uint16', 5125: 'uint32', 5126: 'float32' };
 const ComponentCount = { SCALAR: '', VEC2: 'x2', VEC3: 'x3', VEC4: 'x4', MAT2: 'x8', MAT3: 'x12', MAT4: 'x16' };
 
+const TypedArrayOf = { 5120: Int8Array, 5121: Uint8Array, 5122: Int16Array, 5123: Uint16Array, 5125: Uint32Array, 5126: Float32Array };
+const ComponentsOf = { SCALAR: 1, VEC2: 2, VEC3: 3, VEC4: 4, MAT2: 4, MAT3: 9, MAT4: 16 };
+// neutral stand-ins for material textures a file does not have (RGBA8)
+const DEFAULT_TEXEL = { baseColorURI: [255, 255, 255, 255], metallicRoughnessURI: [255, 255, 255, 255], normalURI: [128, 128, 255, 255],
+  emissiveURI: [0, 0, 0, 255], occlusionURI: [255, 255, 255, 255] };
+
 class glTFLoader {   // eslint-disable-line camelcase -- the reference's class name
-  constructor() {
+  constructor(options = {}) {
+    this.referenceLimits = options.referenceLimits !== false;
     this.pathname = '';
     this.gltf = null;
     this.buffers = [];
@@ -59,6 +70,48 @@ class glTFLoader {   // eslint-disable-line camelcase -- the reference's class n
     return new Float32Array(this.buffers[view.buffer], view.byteOffset || 0, view.byteLength / 4);
   }
 
+  // accessor data as the glTF 2.0 specification lays it out: a flat array of count * components values
+  accessor(index) {
+    const acc = this.gltf.accessors[index];
+    const view = this.gltf.bufferViews[acc.bufferView];
+    const Typed = TypedArrayOf[acc.componentType];
+    const comps = ComponentsOf[acc.type];
+    const size = Typed.BYTES_PER_ELEMENT * comps;
+    const start = (view.byteOffset || 0) + (acc.byteOffset || 0);
+    const stride = view.byteStride || size;
+    const bytes = new Uint8Array(this.buffers[view.buffer]);
+    if (start + (acc.count - 1) * stride + size > bytes.length) throw new Error('Accessor reaches past the end of its buffer.');
+    const packed = new Uint8Array(acc.count * size);
+    for (let i = 0; i < acc.count; ++i) packed.set(bytes.subarray(start + i * stride, start + i * stride + size), i * size);
+    return { data: new Typed(packed.buffer), comps, count: acc.count };
+  }
+
+  generalPrimitive(primitive) {
+    const g = this.gltf;
+    const pos = this.accessor(primitive.attributes.POSITION);
+    const count = pos.count;
+    if (count > 65536) throw new Error('More than 65536 vertices in one primitive: the draw path indexes with 16 bits.');
+    const uv = primitive.attributes.TEXCOORD_0 !== undefined ? this.accessor(primitive.attributes.TEXCOORD_0) : null;
+    const nrm = primitive.attributes.NORMAL !== undefined ? this.accessor(primitive.attributes.NORMAL) : null;
+    const vertices = new Float32Array(count * 8);
+    for (let i = 0; i < count; ++i) {
+      for (let k = 0; k < 3; ++k) vertices[8 * i + k] = pos.data[pos.comps * i + k];
+      for (let k = 0; k < 2; ++k) vertices[8 * i + 3 + k] = uv ? uv.data[uv.comps * i + k] : 0;
+      for (let k = 0; k < 3; ++k) vertices[8 * i + 5 + k] = nrm ? nrm.data[nrm.comps * i + k] : (k === 2 ? 1 : 0);
+    }
+    let indices;
+    if (primitive.indices !== undefined) indices = Uint16Array.from(this.accessor(primitive.indices).data);
+    else indices = Uint16Array.from({ length: count }, (_, i) => i);
+    const material = (g.materials && g.materials[primitive.material || 0]) || {};
+    const pbr = material.pbrMetallicRoughness || {};
+    const uri = (slot) => (slot && slot.index !== undefined ? this.pathname + g.images[g.textures[slot.index].source].uri : null);
+    const textures = {
+      baseColorURI: uri(pbr.baseColorTexture), metallicRoughnessURI: uri(pbr.metallicRoughnessTexture), normalURI: uri(material.normalTexture),
+      emissive: (material.emissiveFactor || [0, 0, 0]).slice(0, 3), emissiveURI: uri(material.emissiveTexture), occlusionURI: uri(material.occlusionTexture),
+    };
+    return { vertices, indices, textures };
+  }
+
   generateGeometries() {
     const g = this.gltf;
     this.geometries = new Array(g.nodes.length);
@@ -74,6 +127,12 @@ class glTFLoader {   // eslint-disable-line camelcase -- the reference's class n
       }
       for (const primitive of g.meshes[node.mesh].primitives) {
         if (primitive.mode !== undefined && primitive.mode !== 4) continue;     // glTF.ts:134-136: triangle lists only
+        if (!this.referenceLimits) {
+          const general = this.generalPrimitive(primitive);
+          this.geometries[index] = { model, vertices: general.vertices, arrayStride: 32, position: { format: 'float32x3', offset: 0 },
+            texCoord: { format: 'float32x2', offset: 12 }, normal: { format: 'float32x3', offset: 20 }, indices: general.indices, textures: general.textures };
+          continue;
+        }
         const posAcc = g.accessors[primitive.attributes.POSITION];
         const uvAcc = g.accessors[primitive.attributes.TEXCOORD_0];
         const nrmAcc = g.accessors[primitive.attributes.NORMAL];
@@ -122,3 +181,4 @@ class glTFLoader {   // eslint-disable-line camelcase -- the reference's class n
 module.exports = glTFLoader;
 module.exports.ComponentType = ComponentType;
 module.exports.ComponentCount = ComponentCount;
+module.exports.DEFAULT_TEXEL = DEFAULT_TEXEL;

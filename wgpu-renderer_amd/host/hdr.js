@@ -1,11 +1,14 @@
 'use strict';
 // Radiance .hdr loader with the reference's surface (src/hdr.ts): `new HDRLoader()`,
 // `await load(url)`, `.hdr` = { width, height, data: Float32Array rgba }.  `url` is a filesystem
-// path.  Same limits as the reference: new-style RLE scanlines only, no special case for e == 0.
+// path.  By default the limits are the reference's: new-style RLE scanlines only, no special case
+// for e == 0.  `new HDRLoader({ referenceLimits: false })` also reads the two older scanline encodings
+// of the format (flat RGBE pixels, and runs marked by a (1,1,1,n) pixel), which the reference rejects.
 const fs = require('fs');
 
 class HDRLoader {
-  constructor() {
+  constructor(options = {}) {
+    this.referenceLimits = options.referenceLimits !== false;
     this.buffer = null;
     this.width = 0;
     this.height = 0;
@@ -50,7 +53,11 @@ class HDRLoader {
     let row = 0;
     while (index < n) {
       if (index + 4 > n || bytes[index] !== 2 || bytes[index + 1] !== 2 || ((bytes[index + 2] << 8) + bytes[index + 3]) !== w) {
-        throw new Error('HDRLoader: Only support RLE format.');                 // hdr.ts:81
+        if (this.referenceLimits) throw new Error('HDRLoader: Only support RLE format.');   // hdr.ts:81
+        if (row >= h) break;
+        index = this.oldScanline(bytes, index, scan, row);
+        row += 1;
+        continue;
       }
       index += 4;
       for (let c = 0; c < 4; ++c) {
@@ -83,5 +90,33 @@ class HDRLoader {
     this.data = data;
   }
 }
+
+// One scanline in the pre-1991 encodings: RGBE pixels one after the other; a pixel (1,1,1,n) repeats the
+// previous pixel n times, consecutive such pixels shifting their counts by 8 bits each.
+HDRLoader.prototype.oldScanline = function oldScanline(bytes, index, scan, row) {
+  const w = this.width;
+  const n = bytes.length;
+  let pos = 0;
+  let shift = 0;
+  while (pos < w) {
+    if (index + 4 > n) throw new Error('HDRLoader: Unexpected end of file.');
+    const r = bytes[index], g = bytes[index + 1], b = bytes[index + 2], e = bytes[index + 3];
+    index += 4;
+    if (r === 1 && g === 1 && b === 1) {
+      const count = e << shift;
+      if (pos === 0 || pos + count > w) throw new Error('HDRLoader: Bad scanline data.');
+      const from = (row * w + pos - 1) * 4;
+      for (let i = 0; i < count; ++i) scan.copyWithin((row * w + pos + i) * 4, from, from + 4);
+      pos += count;
+      shift += 8;
+    } else {
+      const at = (row * w + pos) * 4;
+      scan[at] = r; scan[at + 1] = g; scan[at + 2] = b; scan[at + 3] = e;
+      pos += 1;
+      shift = 0;
+    }
+  }
+  return index;
+};
 
 module.exports = HDRLoader;

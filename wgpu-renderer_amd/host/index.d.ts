@@ -36,13 +36,13 @@ export class Camera {
 }
 
 export class glTFLoader {
-  constructor();
+  constructor(options?: { referenceLimits?: boolean });
   load(url: string): Promise<void>;
   getGeometries(): Geometry[];
 }
 
 export class HDRLoader {
-  constructor();
+  constructor(options?: { referenceLimits?: boolean });
   readonly hdr: HDR;
   load(url: string): Promise<void>;
 }
@@ -56,7 +56,7 @@ export type Frame = { rgba: Uint8Array; vis?: Uint32Array; stats: FrameStats };
 
 export type RendererOptions = {
   width?: number; height?: number; device?: number; modelPath?: string; hdrPath?: string; hdr?: HDR;
-  skyboxSize?: number; irradianceSize?: number; prefilterSize?: number; prefilterMips?: number; lutSize?: number;
+  referenceLimits?: boolean; skyboxSize?: number; irradianceSize?: number; prefilterSize?: number; prefilterMips?: number; lutSize?: number;
 };
 
 export class Renderer {

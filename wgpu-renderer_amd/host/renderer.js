@@ -33,6 +33,7 @@ class Renderer {
     this.prefilterSize = options.prefilterSize || 128;                 // renderer.ts:773
     this.prefilterMips = options.prefilterMips || 5;                   // renderer.ts:1545
     this.lutSize = options.lutSize || 512;                             // renderer.ts:779
+    this.referenceLimits = options.referenceLimits !== false;          // false: glTF read per the specification (see gltf.js)
     // dat.gui defaults, renderer.ts:1762-1768, :1793-1795
     this.textureOptions = { mipmaps: true, addressModeU: 'repeat', addressModeV: 'repeat', magFilter: 'linear', minFilter: 'linear' };
     this.msaaOptions = { enable: false };
@@ -73,7 +74,7 @@ class Renderer {
   }
 
   async loadModel() {
-    const loader = new glTFLoader();                                   // renderer.ts:281-286
+    const loader = new glTFLoader({ referenceLimits: this.referenceLimits });   // renderer.ts:281-286
     await loader.load(this.modelPath);
     this.geometries = loader.getGeometries();
   }
@@ -96,7 +97,10 @@ class Renderer {
     const t = this.geometries[0].textures;
     const slots = [[addon.TEX_ALBEDO, t.baseColorURI, true], [addon.TEX_METALLIC_ROUGHNESS, t.metallicRoughnessURI, false],
       [addon.TEX_NORMAL, t.normalURI, false], [addon.TEX_EMISSIVE, t.emissiveURI, true], [addon.TEX_OCCLUSION, t.occlusionURI, false]];
-    const bitmaps = await Promise.all(slots.map((s) => loadImageBitmap(s[1])));
+    // a loader without the reference's limits may leave a texture out: neutral 1x1 stand-in
+    const names = ['baseColorURI', 'metallicRoughnessURI', 'normalURI', 'emissiveURI', 'occlusionURI'];
+    const bitmaps = await Promise.all(slots.map((s, i) => (s[1] === null
+      ? { width: 1, height: 1, data: new Uint8Array(glTFLoader.DEFAULT_TEXEL[names[i]]) } : loadImageBitmap(s[1]))));
     slots.forEach((s, i) => addon.uploadTexture(this.ctx, s[0], bitmaps[i].data, bitmaps[i].width, bitmaps[i].height, s[2], true));
     const hdr = this.hdrs[0];
     addon.uploadHdr(this.ctx, hdr.data, hdr.width, hdr.height);

@@ -9,16 +9,26 @@ const sha = (typed) => crypto.createHash('sha256').update(Buffer.from(typed.buff
 const hex = (typed) => Buffer.from(typed.buffer, typed.byteOffset, typed.byteLength).toString('hex');
 
 (async () => {
-  const [modelPath, hdrPath, jpegPath] = process.argv.slice(2);
+  const [modelPath, hdrPath, jpegPath, flatPath, oldRlePath, generalModelPath] = process.argv.slice(2);
   const out = {};
   const loader = new host.glTFLoader();
   await loader.load(modelPath);
   const g = loader.getGeometries()[0];
   out.geometry = { vertices: sha(g.vertices), indices: sha(g.indices), model: hex(g.model), arrayStride: g.arrayStride,
     position: g.position, texCoord: g.texCoord, normal: g.normal, textures: g.textures };
+  const general = new host.glTFLoader({ referenceLimits: false });
+  await general.load(generalModelPath);
+  const gg = general.getGeometries()[0];
+  out.generalGeometry = { vertices: sha(gg.vertices), indices: sha(gg.indices), model: hex(gg.model), textures: gg.textures };
   const hdrLoader = new host.HDRLoader();
   await hdrLoader.load(hdrPath);
   out.hdr = { width: hdrLoader.hdr.width, height: hdrLoader.hdr.height, data: sha(hdrLoader.hdr.data) };
+  out.hdrOlder = [];
+  for (const older of [flatPath, oldRlePath]) {
+    const l = new host.HDRLoader({ referenceLimits: false });
+    await l.load(older);
+    out.hdrOlder.push({ width: l.hdr.width, height: l.hdr.height, data: sha(l.hdr.data) });
+  }
   const image = await host.utils.loadImageBitmap(jpegPath);
   out.image = { width: image.width, height: image.height, data: sha(image.data) };
   const r = new host.Renderer({ width: 1280, height: 720, hdr: hdrLoader.hdr });

@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _lib, mathx
 from .camera import Camera
-from .gltf import glTFLoader
+from .gltf import DEFAULT_TEXEL, glTFLoader
 from .hdr import HDR, HDRLoader, synthetic_sky
 from .images import load_image_bitmap
 
@@ -24,7 +24,7 @@ def _fptr(a):
 class Renderer:
     def __init__(self, width=1280, height=720, device=0, model_path=DEFAULT_MODEL, hdr=None,
                  skybox_size=1440, irradiance_size=32, prefilter_size=128, prefilter_mips=5, lut_size=512,
-                 instance_models=None):
+                 instance_models=None, reference_limits=True):
         self.camera = Camera()                                    # renderer.ts:77
         self.width, self.height = int(width), int(height)         # canvas size
         self.device_ordinal = device
@@ -34,6 +34,7 @@ class Renderer:
         self.prefilter_size, self.prefilter_mips = prefilter_size, prefilter_mips  # renderer.ts:773, :1545
         self.lut_size = lut_size                                                   # renderer.ts:779
         self.instance_models = instance_models
+        self.reference_limits = reference_limits                  # False: glTF read per the specification (see gltf.py)
         # dat.gui defaults, renderer.ts:1762-1768, :1793-1795
         self.texture_options = {"mipmaps": True, "addressModeU": "repeat", "addressModeV": "repeat",
                                 "magFilter": "linear", "minFilter": "linear"}
@@ -79,7 +80,7 @@ class Renderer:
         self._ready = True
 
     def load_model(self):
-        loader = glTFLoader()
+        loader = glTFLoader(reference_limits=self.reference_limits)
         loader.load(self.model_path)                               # renderer.ts:281-286
         self.geometries = loader.get_geometries()
 
@@ -114,7 +115,11 @@ class Renderer:
         slots = [(_lib.TEX_ALBEDO, t["baseColorURI"], 1), (_lib.TEX_METALLIC_ROUGHNESS, t["metallicRoughnessURI"], 0),
                  (_lib.TEX_NORMAL, t["normalURI"], 0), (_lib.TEX_EMISSIVE, t["emissiveURI"], 1), (_lib.TEX_OCCLUSION, t["occlusionURI"], 0)]
         for slot, uri, srgb in slots:
-            img = load_image_bitmap(uri)
+            if uri is None:      # only a loader without the reference's limits leaves a texture out: neutral 1x1 stand-in
+                names = ("baseColorURI", "metallicRoughnessURI", "normalURI", "emissiveURI", "occlusionURI")
+                img = np.array([[DEFAULT_TEXEL[names[slot]]]], dtype=np.uint8)
+            else:
+                img = load_image_bitmap(uri)
             self._check(self._lib.pbr_upload_texture(self._ctx, slot, _fptr(img), img.shape[1], img.shape[0], srgb, 1))
         hdr = self.hdrs[0]
         data = np.ascontiguousarray(hdr.data, dtype=np.float32)
