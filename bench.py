@@ -222,19 +222,40 @@ def main():
                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS, "algorithmic_bytes": frame_bytes},
         }
 
-    if rank == 0 and not args.no_prefilter:
-        # second headline figure: the IBL GGX prefilter at 2048^2 x 10 mips x 1024 samples (single GPU here)
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, args.prefilter_size, args.prefilter_mips, 1024, 0, 1))   # allocate + warm
-        torch.cuda.synchronize(dev)
-        ev0.record(lanes[0][1])
-        pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, args.prefilter_size, args.prefilter_mips, 1024, 0, 1))
-        ev1.record(lanes[0][1])
-        torch.cuda.synchronize(dev)
-        ms = ev0.elapsed_time(ev1)
+    if not args.no_prefilter:
+        # second headline figure: the IBL GGX prefilter at 2048^2 x 10 mips x 1024 samples.  One GPU filters
+        # the whole map; with several ranks each filters its texel range and one all-gather (RCCL) makes
+        # the map whole on every GPU.
         texels = sum(6 * max(1, args.prefilter_size >> m) ** 2 for m in range(args.prefilter_mips))
-        result["ibl_prefilter"] = {"ms": ms, "config": f"{args.prefilter_size}^2 cube, {args.prefilter_mips} mips, 1024 samples/texel", "n_gpus": 1,
-                                   "algorithmic_tflops": texels * 1024 * 110 / (ms * 1e-3) / 1e12, "fp32_peak_tflops": 157.3}
+        info = {"config": f"{args.prefilter_size}^2 cube, {args.prefilter_mips} mips, 1024 samples/texel", "n_gpus": world}
+        try:
+            import importlib
+            parallel = importlib.import_module(pkg.__name__ + ".parallel")
+
+            def run_prefilter():
+                if world == 1:
+                    pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, args.prefilter_size, args.prefilter_mips, 1024, 0, 1))
+                else:
+                    parallel.prefilter_sharded(r, args.prefilter_size, args.prefilter_mips, rank, world, dev)
+                torch.cuda.synchronize(dev)
+            run_prefilter()                                   # allocate + warm
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            run_prefilter()
+            if world > 1:
+                dist.barrier()
+            ms = (time.perf_counter() - t0) * 1e3
+            if world > 1:
+                tmax = torch.tensor([ms], dtype=torch.float64, device=dev)
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                ms = float(tmax.item())
+                info["exchange"] = f"all-gather of the {texels * 16 / 1e6:.0f} MB map included"
+            info.update({"ms": ms, "algorithmic_tflops": texels * 1024 * 110 / (ms * 1e-3) / 1e12, "fp32_peak_tflops": 157.3 * world})
+        except Exception as exc:                             # the frame benchmark above stands on its own
+            info["error"] = f"{type(exc).__name__}: {exc}"
+        if rank == 0:
+            result["ibl_prefilter"] = info
         # restore the frame's prefilter map
         pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, r.prefilter_size, r.prefilter_mips, 1024, 0, 1))
         torch.cuda.synchronize(dev)
