@@ -205,6 +205,7 @@ struct PbrContextPrivate {
   struct Bordered { float4* d = nullptr; DevCube cube = {}; bool dirty = true; };
   Bordered sky_b, irr_b, pre_b;
   int surface_blocks = 0;                 // resident workgroups of the surface kernel on this device
+  int counter_set = 0;                    // which of the two sets of append counters the next frame uses
 };
 static PbrContextPrivate* priv_of(PbrContext* c);
 
@@ -214,12 +215,14 @@ struct CtxBox { PbrContext pub; PbrContextPrivate priv; };
 static PbrContextPrivate* priv_of(PbrContext* c) { return &reinterpret_cast<CtxBox*>(c)->priv; }
 
 static int check_sticky(PbrContext* c) {
-  // counters[2] is set by the binning kernels when a capacity was exceeded
-  if (c->h_counters && c->h_counters[2]) {
-    uint32_t code = c->h_counters[2];
-    c->h_counters[2] = 0;
-    (void)hipMemset(&c->d_counters[2], 0, sizeof(uint32_t));
-    return fail(c, PBR_E_STATE, code == 1 ? "triangle setup buffer overflow" : "tile bin overflow list full");
+  // counter [2] of either set is raised by the binning kernels when a capacity was exceeded
+  for (int set = 0; set < 2; ++set) {
+    if (c->h_counters && c->h_counters[8 * set + 2]) {
+      const uint32_t code = c->h_counters[8 * set + 2];
+      c->h_counters[8 * set + 2] = 0;
+      (void)hipMemset(&c->d_counters[8 * set + 2], 0, sizeof(uint32_t));
+      return fail(c, PBR_E_STATE, code == 1 ? "triangle setup buffer overflow" : "tile bin overflow list full");
+    }
   }
   return PBR_OK;
 }
@@ -283,21 +286,6 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], s));
   uint8_t* color = static_cast<uint8_t*>(d_rgba8);
 
-  // The skybox tiles are shared out over the frame's three geometry launches: the vertex and setup
-  // kernels are latency-bound and leave the chip almost idle, so each carries a slice of the tiles as
-  // extra workgroups; the rasteriser shades the rest (each workgroup its own tile).
-  const int n_tiles = tiles_x * tiles_y;
-  static const float share_vertex = getenv("PBR_SKY_SHARE_VERTEX") ? (float)atof(getenv("PBR_SKY_SHARE_VERTEX")) : 0.15f;
-  static const float share_setup = getenv("PBR_SKY_SHARE_SETUP") ? (float)atof(getenv("PBR_SKY_SHARE_SETUP")) : 0.40f;
-  SkyShare sky_a, sky_b;
-  sky_a.sky = pr->sky_b.cube; sky_a.rgba8 = reinterpret_cast<uint32_t*>(color); sky_a.first = 0; sky_a.count = (int)(n_tiles * share_vertex); sky_a.own_blocks = 0;
-  sky_b = sky_a; sky_b.first = sky_a.count; sky_b.count = std::min(n_tiles - sky_a.count, (int)(n_tiles * share_setup));
-  const int sky_from_tile = sky_b.first + sky_b.count;
-  launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances, sky_a);
-  if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
-  launch_setup_and_bin(s, dp, c->d_vout, c->d_indices, c->d_setup, c->d_records, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
-                       (uint32_t)c->overflow_cap, c->d_counters, c->n_indices / 3, c->n_instances, sky_b);
-  if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   // the specialised resolve covers the reference's default sampler on power-of-two textures
   static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
   bool fast = u->sampler_index == 15u;
@@ -305,12 +293,40 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   for (int i = 0; i < 5; ++i)
     fast = fast && (c->tex[i].w & (c->tex[i].w - 1)) == 0 && (c->tex[i].h & (c->tex[i].h - 1)) == 0 && c->tex[i].w == c->tex[0].w &&
            c->tex[i].h == c->tex[0].h && c->tex[i].levels == c->tex[0].levels;
+
+  // two sets of append counters, used by alternate frames (the rasteriser re-arms the next frame's set)
+  uint32_t* counters = c->d_counters + 8 * pr->counter_set;
+  uint32_t* next_counters = c->d_counters + 8 * (1 - pr->counter_set);
+  const int this_set = pr->counter_set;
+  pr->counter_set = 1 - pr->counter_set;
+
+  // The skybox tiles are shared out over the frame's geometry launches: those kernels are
+  // latency-bound and leave the chip almost idle, so each carries a slice of the tiles as extra
+  // workgroups; the rasteriser shades the rest (each workgroup its own tile).
+  const int n_tiles = tiles_x * tiles_y;
+  static const float share_vertex = getenv("PBR_SKY_SHARE_VERTEX") ? (float)atof(getenv("PBR_SKY_SHARE_VERTEX")) : 0.15f;
+  static const float share_setup = getenv("PBR_SKY_SHARE_SETUP") ? (float)atof(getenv("PBR_SKY_SHARE_SETUP")) : 0.40f;
+  SkyShare sky_a, sky_b;
+  sky_a.sky = pr->sky_b.cube; sky_a.rgba8 = reinterpret_cast<uint32_t*>(color); sky_a.first = 0; sky_a.own_blocks = 0;
+  // The specialised frame has no vertex launch: the setup kernel transforms each triangle's vertices from
+  // the streams itself.  The general-sampler resolve reads transformed vertices from memory, so that
+  // frame keeps the vertex launch.
+  sky_a.count = fast ? 0 : (int)(n_tiles * share_vertex);
+  sky_b = sky_a; sky_b.first = sky_a.count; sky_b.count = std::min(n_tiles - sky_a.count, (int)(n_tiles * (fast ? share_vertex + share_setup : share_setup)));
+  const int sky_from_tile = sky_b.first + sky_b.count;
+  VertexSource source = {c->d_vout, nullptr, nullptr, nullptr};
+  if (fast) { source.vsoa = c->d_vsoa; source.inst_model = c->d_inst_model; source.inst_normal = c->d_inst_normal; }
+  else launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances, sky_a);
+  if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
+  launch_setup_and_bin(s, dp, source, c->d_indices, c->d_setup, c->d_records, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
+                       (uint32_t)c->overflow_cap, counters, c->n_indices / 3, c->n_instances, sky_b);
+  if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
   // the visibility buffer is only written when someone will read it: the caller (vis output), the
   // coverage count of the statistics, or the general-sampler resolve
   const bool write_vis = d_vis != nullptr || want_host_vis || timed || !fast;
   launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
-                c->d_counters, c->quad_lists, write_vis, pr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
+                counters, next_counters, c->quad_lists, write_vis, pr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
 
   ResolveInputs in;
@@ -320,7 +336,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   in.irr_b = pr->irr_b.cube; in.pre_b = pr->pre_b.cube; in.sky_b = pr->sky_b.cube;
   in.lut = c->d_lut; in.lut_size = c->lut_size;
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
-  launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->quad_lists, c->d_counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
+  launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->quad_lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
@@ -328,20 +344,21 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   ++pr->frames_drawn;
 
   if (timed) {
-    HIP_TRY(c, hipMemsetAsync(&c->d_counters[3], 0, sizeof(uint32_t), s));
-    launch_count_covered(s, vis, (size_t)W * rows, &c->d_counters[3]);
-    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemsetAsync(&counters[3], 0, sizeof(uint32_t), s));
+    launch_count_covered(s, vis, (size_t)W * rows, &counters[3]);
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     (void)hipEventElapsedTime(&stats->ms_vertex, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&stats->ms_setup, c->ev[1], c->ev[2]);
     (void)hipEventElapsedTime(&stats->ms_raster, c->ev[2], c->ev[3]);
     (void)hipEventElapsedTime(&stats->ms_resolve, c->ev[3], c->ev[4]);
     (void)hipEventElapsedTime(&stats->ms_total, c->ev[0], c->ev[4]);
-    stats->setup_triangles = c->h_counters[0];
-    stats->binned_refs = c->h_counters[1];   // references that spilled past a tile's own row
-    stats->covered_pixels = c->h_counters[3];
-    stats->uniform_quads = c->h_counters[6];
-    stats->mixed_quads = c->h_counters[7];
+    const uint32_t* hc = c->h_counters + 8 * this_set;
+    stats->setup_triangles = hc[0];
+    stats->binned_refs = hc[1];   // references that spilled past a tile's own row
+    stats->covered_pixels = hc[3];
+    stats->uniform_quads = hc[6];
+    stats->mixed_quads = hc[7];
     return check_sticky(c);
   }
   return PBR_OK;
@@ -378,10 +395,10 @@ int pbr_create(int device_ordinal, PbrContext** ctx_out) {
     pr->surface_blocks = dp.multiProcessorCount * surface_fast_blocks_per_cu();
   }
   for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&c->d_counters, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMemset(c->d_counters, 0, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
-  if ((e = hipHostMalloc(&c->h_counters, 8 * sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
-  std::memset(c->h_counters, 0, 8 * sizeof(uint32_t));
+  if ((e = hipMalloc(&c->d_counters, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(c->d_counters, 0, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
+  if ((e = hipHostMalloc(&c->h_counters, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
+  std::memset(c->h_counters, 0, 16 * sizeof(uint32_t));
   if ((e = hipMalloc(&c->d_samples, sizeof(PrefilterSample) * PBR_PREFILTER_SAMPLES * PBR_MAX_LEVELS)) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&c->d_irr_tables, sizeof(float) * 2 * (512 + 128))) != hipSuccess) return bail("hipMalloc", e);
   {
@@ -429,7 +446,7 @@ int pbr_synchronize(PbrContext* c) {
   if (!c) return PBR_E_ARG;
   DeviceGuard guard(c->device);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return check_sticky(c);
 }
 
@@ -737,7 +754,7 @@ int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t 
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(rgba8_out, c->d_color, npix * 4, hipMemcpyDeviceToHost));
   if (vis_out) HIP_TRY(c, hipMemcpy(vis_out, c->d_vis, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return check_sticky(c);
 }
 
@@ -754,7 +771,7 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   fp.W = 32; fp.H = 32; fp.y0 = 0; fp.y1 = 32; fp.tiles_x = 1; fp.tiles_y = 1;
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances; fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
   SkyShare none = {};
-  launch_vertex_stage(c->stream, fp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->d_counters, c->n_verts, c->n_instances, none);
+  launch_vertex_stage(c->stream, fp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances, none);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   const size_t nv = (size_t)c->n_verts * c->n_instances;
   std::vector<VertexOut> host(nv);

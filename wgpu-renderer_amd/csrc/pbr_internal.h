@@ -61,13 +61,14 @@ struct SetupTri {
 };
 
 // Everything the shading resolve needs of one triangle, written by the setup kernel so that a pixel
-// fetches it in one round of loads: 36 words, read as nine 16-byte loads.
+// fetches it in one round of loads: nine 16-byte loads, three more in the rare non-projective case.
 struct TriRecord {
   int32_t X0, Y0, X1, Y1, X2, Y2;   // vertices snapped to 1/256 pixel, in index order (valid when projective)
   float inv_area;                   // 1 / (twice the signed area in snapped units)
   uint32_t projective;              // all w > 0 and inside the guard band: screen-space barycentrics apply
   float iw0, iw1, iw2, pad;         // 1 / w of the vertices
   float pos[9], nrm[9], uv[6];      // world positions, transformed normals, texcoords of the three vertices
+  float clip[12];                   // clip positions; written (and read) only when not projective
 };
 
 // Per-vertex outputs of the vertex stage, laid out for the resolve's gathers.
@@ -131,7 +132,7 @@ struct PbrContext {
   uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0;   // [tiles], [tiles][PBR_BIN_CAP]
   QuadLists quad_lists = {nullptr, nullptr, nullptr};                                  // work lists of the resolve, each [tiles * 256]
   uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
-  uint32_t* d_counters = nullptr; // [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6], [7] uniform and mixed quads holding geometry
+  uint32_t* d_counters = nullptr; // two sets of 8, used by alternate frames: [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6], [7] uniform and mixed quads
   bool capture_depth = false;
   uint32_t* h_counters = nullptr; // pinned mirror
   uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0;
@@ -158,12 +159,15 @@ void launch_brdf_lut(hipStream_t s, uint16_t* out, int size);
 
 struct SkyShare;   // sky_shade.h
 void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa, const float* inst_model, const float* inst_normal,
-                         VertexOut* out, uint32_t* counters, int n_verts, int n_instances, const SkyShare& share);
-void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup, TriRecord* records,
+                         VertexOut* out, int n_verts, int n_instances, const SkyShare& share);
+// where the setup kernel takes a triangle's vertices from: transformed vertices in memory (vout), or the
+// vertex streams, transformed on the fly (vsoa set, vout unused)
+struct VertexSource { const VertexOut* vout; const float* vsoa; const float* inst_model; const float* inst_normal; };
+void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint16_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           int n_tris, int n_instances, const SkyShare& share);
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, const QuadLists& lists, bool write_vis,
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, const QuadLists& lists, bool write_vis,
                    const DevCube& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y);
 struct ResolveInputs {
   const TriRecord* records;

@@ -19,34 +19,44 @@ namespace {
 // Vertex stage.  Attribute streams are SoA (px[], py[], pz[], u[], v[], nx[], ny[], nz[]) so a
 // wavefront's 64 loads of one attribute are one contiguous 256-byte request.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) vertex_kernel(const FrameParams frame_params, const float* __restrict__ vsoa,
-                                                     const float* __restrict__ inst_model, const float* __restrict__ inst_normal,
-                                                     VertexOut* __restrict__ out, uint32_t* __restrict__ counters, int n_verts, int blocks_per_instance,
-                                                     SkyShare share) {
-  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
-  if ((int)blockIdx.x >= share.own_blocks) { sky_tile(p, share.sky, share.rgba8, share.first + (int)blockIdx.x - share.own_blocks); return; }
-  const int inst = (int)blockIdx.x / blocks_per_instance;
-  const int i = ((int)blockIdx.x - inst * blocks_per_instance) * 256 + threadIdx.x;
-  // first kernel of a frame: re-arm the setup-triangle and bin-overflow counters the later kernels append with
-  if (blockIdx.x == 0 && threadIdx.x == 0) { counters[0] = 0u; counters[1] = 0u; counters[6] = 0u; counters[7] = 0u; }
-  if (i >= n_verts) return;
-  float model[16], nmat[16], pvm[16];
+// vs_main (shader.wgsl:37-47) for vertex i of one instance; every product and sum rounded on its own.
+struct VertexMatrices { float model[16], nmat[16], pvm[16]; };
+
+PBR_DEV void load_matrices(const FrameParams* __restrict__ p, const float* __restrict__ inst_model, const float* __restrict__ inst_normal, int inst,
+                           VertexMatrices& m) {
   const float* msrc = p->has_instance_mats ? inst_model + 16 * inst : p->u.model;
   const float* nsrc = p->has_instance_mats ? inst_normal + 16 * inst : p->u.normal;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { model[k] = msrc[k]; nmat[k] = nsrc[k]; }
-  mat4_mul_exact(p->pv, model, pvm);   // (projection * view) * model
-  const size_t n = (size_t)n_verts;
+  for (int k = 0; k < 16; ++k) { m.model[k] = msrc[k]; m.nmat[k] = nsrc[k]; }
+  mat4_mul_exact(p->pv, m.model, m.pvm);   // (projection * view) * model
+}
+
+PBR_DEV VertexOut transform_vertex(const VertexMatrices& m, const float* __restrict__ vsoa, size_t n, int i) {
   const float x = vsoa[i], y = vsoa[n + i], z = vsoa[2 * n + i];
   const float tu = vsoa[3 * n + i], tv = vsoa[4 * n + i];
   const float nx = vsoa[5 * n + i], ny = vsoa[6 * n + i], nz = vsoa[7 * n + i];
   VertexOut o;
-  o.clip = mat4_vec_exact(pvm, x, y, z, 1.0f);
-  float4 w = mat4_vec_exact(model, x, y, z, 1.0f);
-  float4 nn = mat4_vec_exact(nmat, nx, ny, nz, 0.0f);
+  o.clip = mat4_vec_exact(m.pvm, x, y, z, 1.0f);
+  const float4 w = mat4_vec_exact(m.model, x, y, z, 1.0f);
+  const float4 nn = mat4_vec_exact(m.nmat, nx, ny, nz, 0.0f);
   o.world_u = make_float4(w.x, w.y, w.z, tu);
   o.nrm_v = make_float4(nn.x, nn.y, nn.z, tv);
-  out[(size_t)inst * n + i] = o;
+  return o;
+}
+
+// The vertex stage as a launch of its own: used when the vertex outputs are wanted in memory (the
+// general-sampler resolve, verification).  The specialised frame transforms vertices inside the setup kernel.
+__global__ void __launch_bounds__(256) vertex_kernel(const FrameParams frame_params, const float* __restrict__ vsoa,
+                                                     const float* __restrict__ inst_model, const float* __restrict__ inst_normal,
+                                                     VertexOut* __restrict__ out, int n_verts, int blocks_per_instance, SkyShare share) {
+  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
+  if ((int)blockIdx.x >= share.own_blocks) { sky_tile(p, share.sky, share.rgba8, share.first + (int)blockIdx.x - share.own_blocks); return; }
+  const int inst = (int)blockIdx.x / blocks_per_instance;
+  const int i = ((int)blockIdx.x - inst * blocks_per_instance) * 256 + threadIdx.x;
+  if (i >= n_verts) return;
+  VertexMatrices m;
+  load_matrices(p, inst_model, inst_normal, inst, m);
+  out[(size_t)inst * n_verts + i] = transform_vertex(m, vsoa, (size_t)n_verts, i);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -99,6 +109,8 @@ struct BinTargets {
   uint2* overflow; uint32_t overflow_cap;
   uint32_t* counters;
   TriRecord* records;
+  // when vsoa is set the triangle's vertices are transformed here from the vertex streams (and vout is not read)
+  const float* vsoa; const float* inst_model; const float* inst_normal;
 };
 
 PBR_DEV void bin_store(const BinTargets& bt, uint32_t tile, uint32_t pos, uint32_t slot) {
@@ -179,12 +191,22 @@ PBR_DEV void write_record(TriRecord* __restrict__ dst, const VertexOut& a, const
   d[6] = make_float4(b.nrm_v.x, b.nrm_v.y, b.nrm_v.z, c.nrm_v.x);
   d[7] = make_float4(c.nrm_v.y, c.nrm_v.z, a.world_u.w, a.nrm_v.w);
   d[8] = make_float4(b.world_u.w, b.nrm_v.w, c.world_u.w, c.nrm_v.w);
+  if (!projective) { d[9] = ca; d[10] = cb; d[11] = cc; }   // only the homogeneous fallback of the resolve reads these
 }
 
 PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint16_t* indices, const BinTargets& bt, int inst, int t, int n_tris,
                        Deferred* defer) {
   const size_t base = (size_t)inst * p->n_verts;
-  const VertexOut va = vout[base + indices[3 * t]], vb = vout[base + indices[3 * t + 1]], vc = vout[base + indices[3 * t + 2]];
+  const int ia = indices[3 * t], ib = indices[3 * t + 1], ic = indices[3 * t + 2];
+  VertexOut va, vb, vc;
+  if (bt.vsoa) {
+    VertexMatrices m;
+    load_matrices(p, bt.inst_model, bt.inst_normal, inst, m);
+    va = transform_vertex(m, bt.vsoa, (size_t)p->n_verts, ia); vb = transform_vertex(m, bt.vsoa, (size_t)p->n_verts, ib);
+    vc = transform_vertex(m, bt.vsoa, (size_t)p->n_verts, ic);
+  } else {
+    va = vout[base + ia]; vb = vout[base + ib]; vc = vout[base + ic];
+  }
   const float4 a = va.clip, b = vb.clip, c = vc.clip;
   const uint32_t id = (uint32_t)inst * (uint32_t)n_tris + (uint32_t)t;
   const float4 v[3] = {a, b, c};
@@ -276,13 +298,16 @@ PBR_DEV long long bcast64(long long v, int src_lane) {
 __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_params, const SetupTri* __restrict__ setup,
                                                      uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
                                                      const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
-                                                     float* __restrict__ depth, uint32_t* __restrict__ counters, QuadLists lists, int write_vis, DevCube sky,
-                                                     uint32_t* __restrict__ rgba8, int sky_from_tile) {
+                                                     float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters,
+                                                     QuadLists lists, int write_vis, DevCube sky, uint32_t* __restrict__ rgba8, int sky_from_tile) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
   __shared__ uint32_t s_pairs[4], s_base[2];
   const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // The frame's append counters come in two sets used by alternate frames; this launch re-arms the set of
+  // the next frame, which nothing is using (the previous frame, its last user, finished before this launch began).
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
   const int px0 = blockIdx.x * PBR_TILE, py0 = p->y0 + blockIdx.y * PBR_TILE;   // tile origin in pixels
   const uint32_t n = tile_count[tile];
   // the first PBR_BIN_CAP references sit in the tile's own row; a fuller tile also filters the shared overflow list
@@ -482,31 +507,32 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
 }  // namespace
 
 void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa, const float* inst_model, const float* inst_normal,
-                         VertexOut* out, uint32_t* counters, int n_verts, int n_instances, const SkyShare& share_in) {
+                         VertexOut* out, int n_verts, int n_instances, const SkyShare& share_in) {
   const int per_instance = (n_verts + 255) / 256;
   SkyShare share = share_in;
   share.own_blocks = per_instance * n_instances;
-  hipLaunchKernelGGL(vertex_kernel, dim3(share.own_blocks + share.count), dim3(256), 0, s, p, vsoa, inst_model, inst_normal, out, counters, n_verts,
-                     per_instance, share);
+  hipLaunchKernelGGL(vertex_kernel, dim3(share.own_blocks + share.count), dim3(256), 0, s, p, vsoa, inst_model, inst_normal, out, n_verts, per_instance,
+                     share);
 }
 
-void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexOut* vout, const uint16_t* indices, SetupTri* setup, TriRecord* records,
+void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint16_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           int n_tris, int n_instances, const SkyShare& share_in) {
-  // tile_count is zero on entry (the raster kernel of the previous frame clears it) and the vertex
-  // kernel has reset the append counters
+  // tile_count is zero on entry (the raster kernel of the previous frame clears it) and so are the
+  // frame's append counters (re-armed by the raster kernel of the previous frame)
   BinTargets bt;
   bt.setup = setup; bt.setup_cap = setup_cap; bt.tile_count = tile_count; bt.bins = bins; bt.overflow = overflow; bt.overflow_cap = overflow_cap;
   bt.counters = counters; bt.records = records;
+  bt.vsoa = src.vsoa; bt.inst_model = src.inst_model; bt.inst_normal = src.inst_normal;
   const int per_instance = (n_tris + 255) / 256;
   SkyShare share = share_in;
   share.own_blocks = per_instance * n_instances;
-  hipLaunchKernelGGL(setup_kernel, dim3(share.own_blocks + share.count), dim3(256), 0, s, p, vout, indices, bt, n_tris, per_instance, share);
+  hipLaunchKernelGGL(setup_kernel, dim3(share.own_blocks + share.count), dim3(256), 0, s, p, src.vout, indices, bt, n_tris, per_instance, share);
 }
 
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, const QuadLists& lists, bool write_vis,
+                   uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, const QuadLists& lists, bool write_vis,
                    const DevCube& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y) {
   hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
-                     lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile);
+                     next_counters, lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile);
 }

@@ -599,10 +599,7 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
     qb.iw0 = r2.x; qb.iw1 = r2.y; qb.iw2 = r2.z;
   } else {
     // a vertex behind the eye or beyond the guard band (rare): the homogeneous form needs the clip positions
-    uint32_t inst = 0, tri = tri_id;
-    if (p->n_instances > 1) { inst = tri / (uint32_t)p->n_tris; tri -= inst * (uint32_t)p->n_tris; }
-    const VertexOut* vb = in.vout + (size_t)inst * p->n_verts;
-    t.c0 = vb[in.indices[3 * tri]].clip; t.c1 = vb[in.indices[3 * tri + 1]].clip; t.c2 = vb[in.indices[3 * tri + 2]].clip;
+    t.c0 = rec[9]; t.c1 = rec[10]; t.c2 = rec[11];
   }
   Varyings f, h0, h1, h2;
   if constexpr (UNIFORM) {
