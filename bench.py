@@ -142,8 +142,9 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
-    # the dominant kernel is timed on the first context's stream, on the frames that context renders
-    pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, (args.steps + K - 1) // K + 1))
+    # the dominant kernel is timed on the first context's stream, on the first quarter (at least eight) of
+    # the frames that context renders in the timed region: an event pair costs about 10 us of stream time
+    pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, max(8, (args.steps + K - 1) // K // 4)))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
