@@ -1,7 +1,8 @@
-// gfx950 deferred shading resolve: reads the triangle-id visibility buffer and produces the
-// frame's colour.  Covered pixels run the arithmetic of fs_main in src/shaders/shader.wgsl:93-160
-// (normal mapping from screen-space derivatives, four point lights with Cook-Torrance, split-sum
-// IBL, gamma); background pixels run fs_main of src/shaders/skybox.wgsl:24-33.
+// gfx950 deferred shading resolve: produces the colour of the covered pixels from the rasteriser's
+// visibility data (the quad work lists, or the triangle-id buffer for the general kernel) with the
+// arithmetic of fs_main in src/shaders/shader.wgsl:93-160 (normal mapping from screen-space
+// derivatives, four point lights with Cook-Torrance, split-sum IBL, gamma).  Background pixels get
+// fs_main of src/shaders/skybox.wgsl:24-33 in the geometry launches (sky_shade.h).
 //
 // A hardware rasteriser shades 2x2 quads so that dpdx/dpdy and implicit texture LODs exist.  Here
 // every covered pixel re-derives its quad on its own triangle: the varyings are evaluated at the
@@ -10,7 +11,7 @@
 // normal map, so the normal-mapped reflection vector is evaluated at those three pixels as well.
 // Four consecutive lanes hold one 2x2 quad; when all four pixels of a quad show the same triangle
 // the three helper evaluations are the neighbours' own results and are fetched with cross-lane
-// reads instead of being recomputed.  Background pixels are shaded by a separate, light kernel.
+// reads instead of being recomputed.
 //
 // Sampling rules: lambda = log2(max(rho_x, rho_y)) with Euclidean rho; the material sampler has
 // mipmapFilter "nearest" (level ceil(lambda+0.5)-1) and picks magFilter when lambda <= 0; cube
@@ -519,10 +520,10 @@ __global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams 
 }
 
 // ---------------------------------------------------------------------------------------------
-// The specialised surface kernel.  Same arithmetic as resolve_surface_kernel<true>, arranged so that
-// a pixel's memory accesses happen in five rounds of independent loads — visibility id, indices,
-// vertices, all material texels (own pixel and helpers), all IBL texels — instead of one round per
-// lookup: the kernel is latency-bound, so the number of dependent rounds sets its speed.
+// The specialised surface kernel.  Same arithmetic as the FAST branch of the general kernel, arranged so
+// that a pixel's memory accesses happen in four sets of independent loads — list entry, triangle
+// record, all material texels (own pixel and helpers), all IBL texels — instead of one per lookup:
+// each set costs a memory latency, so their number sets the time a wavefront needs per item.
 // ---------------------------------------------------------------------------------------------
 template <bool SRGB>
 PBR_DEV V3 decode_fast(const uint32_t t[4], const Footprint& f, const float* s_srgb) {
@@ -575,7 +576,7 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   const bool cov = live && id != 0u;
   const size_t o = (size_t)(y - p->y0) * p->W + x;
 
-  // round 1: the triangle's record (idle lanes read triangle 0; their results are unused)
+  // first dependent load: the triangle's record (idle lanes read triangle 0; their results are unused)
   const uint32_t tri_id = cov ? id - 1u : 0u;
   const float4* rec = reinterpret_cast<const float4*>(in.records + tri_id);
   const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7], r8 = rec[8];
@@ -619,7 +620,7 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   const DevTex8& tx0 = in.tex[0];
   const int level = lod_2d(tx0.w, tx0.h, p->u.use_mipmaps ? tx0.levels : 1, 15u, duvdx, duvdy).level;
 
-  // round 3: every material texel of this pixel, and the normal-map texels of the helper pixels
+  // second dependent load: every material texel of this pixel, and the normal-map texels of the helper pixels
   const Footprint fp = footprint_fast(tx0, level, f.uv.x, f.uv.y);
   uint32_t t_nrm[4], t_mr[4], t_alb[4], t_emi[4], t_occ[4], t_h0[4], t_h1[4], t_h2[4];
   load4(in.tex[PBR_TEX_NORMAL].base, fp, t_nrm);
@@ -647,7 +648,7 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   const V3 mr = decode_fast<false>(t_mr, fp, s_srgb);
   const float metalness = mr.z, roughness = mr.y;
 
-  // round 4: irradiance (one level), prefilter (two levels of the implicit LOD), BRDF table
+  // third dependent load: irradiance (one level), prefilter (two levels of the implicit LOD), BRDF table
   float lambda = cube_lambda(in.pre.size, R, R1 - R0, R2 - R0);
   if (isnan(lambda)) lambda = 0.0f;
   lambda = fminf(fmaxf(lambda, 0.0f), (float)(in.pre.levels - 1));
