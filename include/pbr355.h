@@ -60,7 +60,7 @@ typedef struct PbrFrameUniforms {
   float light_pos[4][4];    /* shader.wgsl:23, renderer.ts:1887-1894 (vec3 in 16-byte slots) */
   float light_color[4][4];  /* shader.wgsl:24, renderer.ts:1905-1912 */
   float emissive_factor[4]; /* shader.wgsl:28, renderer.ts:614-626 */
-  uint32_t sampler_index;   /* renderer.ts:1927-1932: 1 U repeat | 2 V repeat | 4 mag linear | 8 min linear; bit 16 (MSAA) is rejected */
+  uint32_t sampler_index;   /* renderer.ts:1927-1932: 1 U repeat | 2 V repeat | 4 mag linear | 8 min linear | 16 four samples per pixel (MSAA) */
   uint32_t use_mipmaps;     /* renderer.ts:1977: material textures sampled with their mip chains */
   uint32_t reserved[2];
 } PbrFrameUniforms;
@@ -73,7 +73,7 @@ typedef struct PbrFrameStats {
   float ms_raster;      /* tile rasteriser */
   float ms_resolve;     /* deferred shading resolve */
   float ms_total;       /* first launch to last completion */
-  uint32_t covered_pixels;   /* pixels whose visibility entry is a triangle */
+  uint32_t covered_pixels;   /* pixels whose visibility entry (any of the four with MSAA) is a triangle */
   uint32_t binned_refs;      /* triangle-tile references that spilled past a tile's own bin row */
   uint32_t setup_triangles;  /* front-facing (sub)triangles after clipping and culling */
   uint32_t uniform_quads;    /* 2x2 pixel quads whose four pixels show one triangle */
@@ -131,7 +131,12 @@ int pbr_ibl_prefilter_shard_range(PbrContext* ctx, int32_t shard_index, int32_t 
  * Renders rows [y0,y1) of a w x h target (y0,y1 even, or y1==h) with the helmet draw
  * (drawIndexed, renderer.ts:2006) followed by the skybox draw (renderer.ts:2011).
  * rgba8_out: (y1-y0)*w*4 bytes, R,G,B,A per pixel; vis_out (optional): (y1-y0)*w uint32, triangle
- * id + 1 with instance i's triangles offset by i*n_indices/3, 0 where the skybox shows. */
+ * id + 1 with instance i's triangles offset by i*n_indices/3, 0 where the skybox shows.
+ * With bit 16 of u->sampler_index set the frame goes through the 4x multisampled pipeline
+ * (renderer.ts:243-259, :492-501, :1951-1954): coverage and depth per sample at the standard sample
+ * points, each triangle of a pixel shaded once at the pixel centre, the target resolved to the
+ * average of the four samples.  vis_out / d_vis then hold four uint32 per pixel (sample order) and
+ * pbr_debug_depth four floats per pixel. */
 int pbr_draw_frame(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1,
                    uint8_t* rgba8_out, uint32_t* vis_out, PbrFrameStats* stats);
 /* Same pass with outputs left in device memory (d_vis may be NULL); returns without synchronising

@@ -340,7 +340,7 @@ inline float plane_dist(int p, V4 c) {
 }
 
 // Emits the snapped, front-facing setup record of one (sub)triangle, or nothing.
-void emit_triangle(uint32_t id, V4 a, V4 b, V4 c, int W, int H, int y0, int y1, std::vector<SetupTri>& out) {
+void emit_triangle(uint32_t id, V4 a, V4 b, V4 c, int W, int H, int y0, int y1, bool msaa, std::vector<SetupTri>& out) {
   Snapped s[3] = {snap(a, W, H), snap(b, W, H), snap(c, W, H)};
   int64_t area2 = (int64_t)(s[1].X - s[0].X) * (s[2].Y - s[0].Y) - (int64_t)(s[2].X - s[0].X) * (s[1].Y - s[0].Y);
   if (area2 >= 0) return;            // back-facing (clockwise on screen) or zero area: cullMode "back"
@@ -352,16 +352,22 @@ void emit_triangle(uint32_t id, V4 a, V4 b, V4 c, int W, int H, int y0, int y1, 
   t.area = -area2;
   int minX = std::min(s[0].X, std::min(s[1].X, s[2].X)), maxX = std::max(s[0].X, std::max(s[1].X, s[2].X));
   int minY = std::min(s[0].Y, std::min(s[1].Y, s[2].Y)), maxY = std::max(s[0].Y, std::max(s[1].Y, s[2].Y));
-  // pixel centres px*256+128 inside [min, max]
-  t.minx = std::max((minX - 128 + 255) >> 8, 0);
-  t.maxx = std::min((maxX - 128) >> 8, W - 1);
-  t.miny = std::max((minY - 128 + 255) >> 8, y0);
-  t.maxy = std::min((maxY - 128) >> 8, y1 - 1);
+  if (msaa) {
+    // every pixel whose square meets [min, max]: its sample points lie strictly inside the square
+    t.minx = std::max(minX >> 8, 0); t.maxx = std::min(maxX >> 8, W - 1);
+    t.miny = std::max(minY >> 8, y0); t.maxy = std::min(maxY >> 8, y1 - 1);
+  } else {
+    // pixel centres px*256+128 inside [min, max]
+    t.minx = std::max((minX - 128 + 255) >> 8, 0);
+    t.maxx = std::min((maxX - 128) >> 8, W - 1);
+    t.miny = std::max((minY - 128 + 255) >> 8, y0);
+    t.maxy = std::min((maxY - 128) >> 8, y1 - 1);
+  }
   if (t.minx > t.maxx || t.miny > t.maxy) return;
   out.push_back(t);
 }
 
-void setup_triangle(uint32_t id, V4 a, V4 b, V4 c, int W, int H, int y0, int y1, std::vector<SetupTri>& out) {
+void setup_triangle(uint32_t id, V4 a, V4 b, V4 c, int W, int H, int y0, int y1, bool msaa, std::vector<SetupTri>& out) {
   const V4 v[3] = {a, b, c};
   bool inside_all = true;
   for (int p = 0; p < 6; ++p) {
@@ -376,7 +382,7 @@ void setup_triangle(uint32_t id, V4 a, V4 b, V4 c, int W, int H, int y0, int y1,
     for (int k = 0; k < 3; ++k) { l += v[k].x < -v[k].w; r += v[k].x > v[k].w; bt += v[k].y < -v[k].w; tp += v[k].y > v[k].w; }
     if (l == 3 || r == 3 || bt == 3 || tp == 3) return;
   }
-  if (inside_all) { emit_triangle(id, a, b, c, W, H, y0, y1, out); return; }
+  if (inside_all) { emit_triangle(id, a, b, c, W, H, y0, y1, msaa, out); return; }
   // Sutherland-Hodgman against the six planes; the polygon is fanned from its first vertex.
   V4 poly[16], tmp[16];
   int n = 3;
@@ -395,25 +401,33 @@ void setup_triangle(uint32_t id, V4 a, V4 b, V4 c, int W, int H, int y0, int y1,
     n = m;
     std::memcpy(poly, tmp, sizeof(V4) * n);
   }
-  for (int k = 1; k + 1 < n; ++k) emit_triangle(id, poly[0], poly[k], poly[k + 1], W, H, y0, y1, out);
+  for (int k = 1; k + 1 < n; ++k) emit_triangle(id, poly[0], poly[k], poly[k + 1], W, H, y0, y1, msaa, out);
 }
 
 inline V4 load4(const float* p) { return {p[0], p[1], p[2], p[3]}; }
 inline V3 load3(const float* p) { return {p[0], p[1], p[2]}; }
 
-void raster_impl(Ctx& cx, int y0, int y1, uint32_t* vis, float* depth) {
+// Sample positions inside a pixel, in 1/256 pixel: the centre, or the standard four-sample pattern of
+// D3D / Vulkan / Metal that WebGPU's `count: 4` (renderer.ts:492-501) maps to:
+// (0.375, 0.125), (0.875, 0.375), (0.125, 0.625), (0.625, 0.875).
+const int SAMPLE_X[4] = {96, 224, 32, 160}, SAMPLE_Y[4] = {32, 96, 160, 224};
+
+// vis / depth hold `samples` entries per pixel ([y][x][sample]).  Coverage, the depth value and the depth
+// test are per sample; the triangle id a sample keeps is what the fragment stage later shades.
+void raster_impl(Ctx& cx, int y0, int y1, int samples, uint32_t* vis, float* depth) {
   const OrcScene* sc = cx.sc;
   const int W = cx.W, H = cx.H;
+  const bool msaa = samples > 1;
   std::vector<SetupTri> tris;
   for (int inst = 0; inst < sc->n_instances; ++inst)
     for (int t = 0; t < cx.n_tris; ++t) {
       int64_t base = (int64_t)inst * sc->n_verts;
       const uint16_t* ix = sc->indices + 3 * (int64_t)t;
       setup_triangle((uint32_t)(inst * (int64_t)cx.n_tris + t), load4(&cx.clip[4 * (base + ix[0])]),
-                     load4(&cx.clip[4 * (base + ix[1])]), load4(&cx.clip[4 * (base + ix[2])]), W, H, y0, y1, tris);
+                     load4(&cx.clip[4 * (base + ix[1])]), load4(&cx.clip[4 * (base + ix[2])]), W, H, y0, y1, msaa, tris);
     }
   const int rows = y1 - y0;
-  for (int64_t i = 0; i < (int64_t)rows * W; ++i) { vis[i] = 0; depth[i] = 1.0f; }   // renderer.ts:1943-1966
+  for (int64_t i = 0; i < (int64_t)rows * W * samples; ++i) { vis[i] = 0; depth[i] = 1.0f; }   // renderer.ts:1943-1966
   const int BAND = 32;
   const int n_bands = (rows + BAND - 1) / BAND;
 #pragma omp parallel for schedule(dynamic, 1)
@@ -430,23 +444,22 @@ void raster_impl(Ctx& cx, int y0, int y1, uint32_t* vis, float* depth) {
         tl[k] = dy < 0 || (dy == 0 && dx > 0);   // left edge, or top edge
       }
       const float inv_area = 1.0f / (float)t.area;
-      for (int y = ya; y <= yb; ++y) {
-        int64_t py = (int64_t)y * 256 + 128;
-        for (int x = t.minx; x <= t.maxx; ++x) {
-          int64_t px = (int64_t)x * 256 + 128;
-          int64_t E[3];
-          bool in = true;
-          for (int k = 0; k < 3; ++k) {
-            E[k] = B[k] * (py - ay[k]) + A[k] * (px - ax[k]);
-            in = in && (E[k] > 0 || (E[k] == 0 && tl[k]));
+      for (int y = ya; y <= yb; ++y)
+        for (int x = t.minx; x <= t.maxx; ++x)
+          for (int sidx = 0; sidx < samples; ++sidx) {
+            int64_t px = (int64_t)x * 256 + (msaa ? SAMPLE_X[sidx] : 128), py = (int64_t)y * 256 + (msaa ? SAMPLE_Y[sidx] : 128);
+            int64_t E[3];
+            bool in = true;
+            for (int k = 0; k < 3; ++k) {
+              E[k] = B[k] * (py - ay[k]) + A[k] * (px - ax[k]);
+              in = in && (E[k] > 0 || (E[k] == 0 && tl[k]));
+            }
+            if (!in) continue;
+            float l1 = (float)E[1] * inv_area, l2 = (float)E[2] * inv_area;
+            float z = (t.z0 + l1 * t.dz1) + l2 * t.dz2;
+            int64_t o = ((int64_t)(y - y0) * W + x) * samples + sidx;
+            if (z < depth[o]) { depth[o] = z; vis[o] = t.id + 1; }
           }
-          if (!in) continue;
-          float l1 = (float)E[1] * inv_area, l2 = (float)E[2] * inv_area;
-          float z = (t.z0 + l1 * t.dz1) + l2 * t.dz2;
-          int64_t o = (int64_t)(y - y0) * W + x;
-          if (z < depth[o]) { depth[o] = z; vis[o] = t.id + 1; }
-        }
-      }
     }
   }
 }
@@ -655,7 +668,11 @@ Ctx make_ctx(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H) {
   return cx;
 }
 
-void shade_impl(Ctx& cx, int y0, int y1, const uint32_t* vis, uint8_t* rgba8) {
+// With `samples` > 1 every triangle seen by a pixel's samples is shaded once, at the pixel centre
+// ("center" interpolation, the WGSL default), the 8-bit result is what its samples store, and the
+// resolve averages the stored values (round half to even; the rounding of a multisample resolve is
+// left to the implementation).  The skybox triangle covers the samples no geometry claimed.
+void shade_impl(Ctx& cx, int y0, int y1, int samples, const uint32_t* vis, uint8_t* rgba8) {
   const OrcScene* sc = cx.sc;
   const OrcFrameUniforms* u = cx.u;
   Material m;
@@ -669,8 +686,30 @@ void shade_impl(Ctx& cx, int y0, int y1, const uint32_t* vis, uint8_t* rgba8) {
   for (int y = y0; y < y1; ++y)
     for (int x = 0; x < W; ++x) {
       int64_t o = (int64_t)(y - y0) * W + x;
-      if (vis[o]) shade_pixel(cx, m, irr, pre, vis[o] - 1, x, y, rgba8 + 4 * o);
-      else shade_sky(cx, sky, x, y, rgba8 + 4 * o);
+      if (samples == 1) {
+        if (vis[o]) shade_pixel(cx, m, irr, pre, vis[o] - 1, x, y, rgba8 + 4 * o);
+        else shade_sky(cx, sky, x, y, rgba8 + 4 * o);
+        continue;
+      }
+      const uint32_t* ids = vis + o * samples;
+      int sum[3] = {0, 0, 0};
+      for (int a = 0; a < samples; ++a) {
+        bool seen = false;
+        for (int b = 0; b < a; ++b) seen = seen || ids[b] == ids[a];
+        if (seen) continue;
+        int count = 0;
+        for (int b = a; b < samples; ++b) count += ids[b] == ids[a];
+        uint8_t c[4];
+        if (ids[a]) shade_pixel(cx, m, irr, pre, ids[a] - 1, x, y, c);
+        else shade_sky(cx, sky, x, y, c);
+        for (int k = 0; k < 3; ++k) sum[k] += count * c[k];
+      }
+      for (int k = 0; k < 3; ++k) {
+        int q = sum[k] / samples, rem = sum[k] % samples;   // samples == 4
+        if (2 * rem > samples || (2 * rem == samples && (q & 1))) ++q;
+        rgba8[4 * o + k] = (uint8_t)q;
+      }
+      rgba8[4 * o + 3] = 255;
     }
 }
 
@@ -682,26 +721,32 @@ void orc_vertex_transform(const OrcScene* sc, const OrcFrameUniforms* u, float* 
   run_vertex_stage(sc, u, clip, world, nrm);
 }
 
+// Bit 16 of the sampler index selects the 4x multisampled pipeline (renderer.ts:1927-1932, :1951-1954);
+// vis and depth then hold four entries per pixel.
+static int sample_count(const OrcFrameUniforms* u) { return (u->sampler_index & 16u) ? 4 : 1; }
+
 void orc_raster(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int y0, int y1, uint32_t* vis, float* depth) {
   Ctx cx = make_ctx(sc, u, W, H);
+  const int samples = sample_count(u);
   std::vector<float> d;
-  if (!depth) { d.resize((size_t)(y1 - y0) * W); depth = d.data(); }
-  raster_impl(cx, y0, y1, vis, depth);
+  if (!depth) { d.resize((size_t)(y1 - y0) * W * samples); depth = d.data(); }
+  raster_impl(cx, y0, y1, samples, vis, depth);
 }
 
 void orc_shade(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int y0, int y1, const uint32_t* vis, uint8_t* rgba8) {
   Ctx cx = make_ctx(sc, u, W, H);
-  shade_impl(cx, y0, y1, vis, rgba8);
+  shade_impl(cx, y0, y1, sample_count(u), vis, rgba8);
 }
 
 void orc_draw_frame(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int y0, int y1, uint8_t* rgba8, uint32_t* vis_or_null) {
   Ctx cx = make_ctx(sc, u, W, H);
+  const int samples = sample_count(u);
   std::vector<uint32_t> v;
-  std::vector<float> d((size_t)(y1 - y0) * W);
+  std::vector<float> d((size_t)(y1 - y0) * W * samples);
   uint32_t* vis = vis_or_null;
-  if (!vis) { v.resize((size_t)(y1 - y0) * W); vis = v.data(); }
-  raster_impl(cx, y0, y1, vis, d.data());
-  shade_impl(cx, y0, y1, vis, rgba8);
+  if (!vis) { v.resize((size_t)(y1 - y0) * W * samples); vis = v.data(); }
+  raster_impl(cx, y0, y1, samples, vis, d.data());
+  shade_impl(cx, y0, y1, samples, vis, rgba8);
 }
 
 void orc_sample_cube(const float* chain, int size, int levels, const float* dir3, float lod, float* rgba_out) {

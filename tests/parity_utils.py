@@ -21,6 +21,12 @@ def copy_uniforms(src, dst_type):
     return dst
 
 
+def vis_shape(uniforms, rows, W):
+    """One triangle id per pixel, or four (one per sample) when bit 16 of the sampler index selects
+    the multisampled pipeline (renderer.ts:1927-1932)."""
+    return (rows, W, 4) if uniforms.sampler_index & 16 else (rows, W)
+
+
 class OracleScene:
     """Everything the oracle's frame functions need, computed by the oracle itself."""
 
@@ -83,7 +89,7 @@ class OracleScene:
         sc = self.c_scene()
         u = copy_uniforms(uniforms, ob.FrameUniforms)
         rgba = np.zeros((y1 - y0, W, 4), dtype=np.uint8)
-        vis = np.zeros((y1 - y0, W), dtype=np.uint32)
+        vis = np.zeros(vis_shape(uniforms, y1 - y0, W), dtype=np.uint32)
         self.lib.orc_draw_frame(C.byref(sc), C.byref(u), W, H, y0, y1, ob.ptr(rgba), ob.ptr(vis))
         return rgba, vis
 
@@ -91,8 +97,8 @@ class OracleScene:
         y1 = H if y1 is None else y1
         sc = self.c_scene()
         u = copy_uniforms(uniforms, ob.FrameUniforms)
-        vis = np.zeros((y1 - y0, W), dtype=np.uint32)
-        depth = np.zeros((y1 - y0, W), dtype=np.float32)
+        vis = np.zeros(vis_shape(uniforms, y1 - y0, W), dtype=np.uint32)
+        depth = np.zeros(vis.shape, dtype=np.float32)
         self.lib.orc_raster(C.byref(sc), C.byref(u), W, H, y0, y1, ob.ptr(vis), ob.ptr(depth))
         return vis, depth
 

@@ -242,7 +242,7 @@ def _identity_uniforms():
     return u
 
 
-def _raster(verts_xyz, tris, W, H):
+def _raster(verts_xyz, tris, W, H, msaa=False):
     lib = ob.load()
     v = np.zeros((len(verts_xyz), 8), np.float32)
     v[:, :3] = verts_xyz
@@ -250,7 +250,9 @@ def _raster(verts_xyz, tris, W, H):
     idx = np.asarray(tris, np.uint16).reshape(-1)
     sc = _tiny_scene(v, idx)
     u = _identity_uniforms()
-    vis = np.zeros((H, W), np.uint32); depth = np.zeros((H, W), np.float32)
+    u.sampler_index = 16 if msaa else 0
+    shape = (H, W, 4) if msaa else (H, W)
+    vis = np.zeros(shape, np.uint32); depth = np.zeros(shape, np.float32)
     lib.orc_raster(C.byref(sc), C.byref(u), W, H, 0, H, ob.ptr(vis), ob.ptr(depth))
     return vis, depth
 
@@ -273,6 +275,37 @@ def test_raster_fill_rule_partitions_a_quad():
     vis, _ = _raster(q2, [(0, 1, 2), (0, 2, 3)], W, H)
     cov = vis > 0
     assert cov[2:5, 4:10].all() and cov.sum() == 3 * 6
+
+
+def test_multisampled_raster_covers_the_standard_sample_points():
+    """Four samples per pixel at (0.375, 0.125), (0.875, 0.375), (0.125, 0.625), (0.625, 0.875):
+    a rectangle whose edges cut pixels in half keeps exactly the samples on its side, a full-screen
+    quad is partitioned sample by sample, and depth is evaluated at the sample, not the centre."""
+    W, H = 16, 8
+    def ndc(px, py, z=0.25):
+        return (px / W * 2 - 1, 1 - py / H * 2, z)
+    x0, x1, y0, y1 = 4.5, 10.5, 2.5, 5.5
+    q = [ndc(x0, y1), ndc(x1, y1), ndc(x1, y0), ndc(x0, y0)]
+    vis, _ = _raster(q, [(0, 1, 2), (0, 2, 3)], W, H, msaa=True)
+    cov = vis > 0
+    sx = np.array([0.375, 0.875, 0.125, 0.625]); sy = np.array([0.125, 0.375, 0.625, 0.875])
+    ys, xs = np.mgrid[0:H, 0:W]
+    px = xs[..., None] + sx; py = ys[..., None] + sy
+    expect = (px >= x0) & (px < x1) & (py >= y0) & (py < y1)
+    assert (cov == expect).all()
+    assert cov[3, 4].tolist() == [False, True, False, True]       # left edge at x = 4.5 splits pixel 4
+    assert cov[2, 6].tolist() == [False, False, True, True]       # top edge at y = 2.5 splits row 2
+    assert cov[3, 6].all()
+    full = [(-1, -1, 0.5), (1, -1, 0.5), (1, 1, 0.5), (-1, 1, 0.5)]
+    vis, depth = _raster(full, [(0, 1, 2), (0, 2, 3)], W, H, msaa=True)
+    assert (vis > 0).all() and set(np.unique(vis)) == {1, 2} and (depth == 0.5).all()
+    # the diagonal y = 8 - x/2 crosses pixel (0, 7) below all samples but the last one
+    assert vis[7, 0].tolist() == [2, 2, 2, 1] and vis[0, 0].tolist() == [2, 2, 2, 2]
+    # depth slopes with x only: z = 0.25 + 0.5 * x/W, read back at each sample's own x
+    slope = [(-1, -1, 0.25), (1, -1, 0.75), (1, 1, 0.75), (-1, 1, 0.25)]
+    _, depth = _raster(slope, [(0, 1, 2), (0, 2, 3)], W, H, msaa=True)
+    np.testing.assert_allclose(depth, np.broadcast_to(0.25 + 0.5 * px / W, depth.shape), atol=1e-6)
+    assert (np.diff(depth[0, 0][[2, 0, 3, 1]]) > 0).all()
 
 
 def test_raster_culls_back_faces_and_resolves_depth():

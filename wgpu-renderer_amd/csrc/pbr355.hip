@@ -139,7 +139,7 @@ int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out,
   return n;
 }
 
-int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
+int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int samples) {
   const size_t nv = (size_t)c->n_verts * c->n_instances;
   const size_t ntri = (size_t)(c->n_indices / 3) * c->n_instances;
   bool grew = false;
@@ -180,11 +180,16 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles) {
   const size_t npix = (size_t)W * rows;
   if (npix > c->pix_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
-    HIP_TRY(c, hipMalloc(&c->d_vis, npix * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc(&c->d_depth, npix * sizeof(float)));
+    free_dev(c->d_color);
     HIP_TRY(c, hipMalloc(&c->d_color, npix * 4));
     c->pix_cap = npix; grew = true;
+  }
+  if (npix * samples > c->vis_cap) {   // one entry per sample
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_vis); free_dev(c->d_depth);
+    HIP_TRY(c, hipMalloc(&c->d_vis, npix * samples * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc(&c->d_depth, npix * samples * sizeof(float)));
+    c->vis_cap = npix * samples; grew = true;
   }
   (void)grew;
   return PBR_OK;
@@ -252,7 +257,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   if (!u) return fail(c, PBR_E_ARG, "uniforms pointer is null");
   if (W <= 0 || H <= 0 || W > 16384 || H > 16384) return fail(c, PBR_E_ARG, "bad target size %dx%d", W, H);
   if (y0 < 0 || y1 > H || y0 >= y1 || (y0 & 1) || ((y1 & 1) && y1 != H)) return fail(c, PBR_E_ARG, "bad row range [%d,%d) for height %d (rows must start and end on even lines)", y0, y1, H);
-  if (u->sampler_index & ~15u) return fail(c, PBR_E_UNSUPPORTED, "sampler index %u selects the MSAA pipeline, which is not implemented", u->sampler_index);
+  if (u->sampler_index & ~31u) return fail(c, PBR_E_ARG, "sampler index %u: the reference builds 32 samplers (renderer.ts:822-859)", u->sampler_index);
   if (!c->d_vsoa) return fail(c, PBR_E_STATE, "no mesh uploaded");
   for (int i = 0; i < 5; ++i) if (!c->d_tex[i]) return fail(c, PBR_E_STATE, "material texture slot %d not uploaded", i);
   if (!c->d_irr) return fail(c, PBR_E_STATE, "irradiance map not generated");
@@ -265,7 +270,10 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
 
   const int rows = y1 - y0;
   const int tiles_x = (W + PBR_TILE - 1) / PBR_TILE, tiles_y = (rows + PBR_TILE - 1) / PBR_TILE;
-  int rc = ensure_frame_buffers(c, W, rows, tiles_x * tiles_y);
+  // bit 16 of the sampler index selects the multisampled pipeline (renderer.ts:1927-1932, :1951-1954, :1979-1980)
+  const bool msaa = (u->sampler_index & 16u) != 0u;
+  const int samples = msaa ? 4 : 1;
+  int rc = ensure_frame_buffers(c, W, rows, tiles_x * tiles_y, samples);
   if (rc) return rc;
 
   // per-frame parameters travel as kernel arguments
@@ -275,6 +283,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   fp.W = W; fp.H = H; fp.y0 = y0; fp.y1 = y1; fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances;
   fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
+  fp.msaa = msaa ? 1 : 0;
   const FrameParams& dp = fp;
   hipStream_t s = c->stream;
 
@@ -288,7 +297,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
 
   // the specialised resolve covers the reference's default sampler on power-of-two textures
   static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
-  bool fast = u->sampler_index == 15u;
+  bool fast = (u->sampler_index & 15u) == 15u;
   for (int i = 0; i < 5; ++i) fast = fast && c->tex[i].srgb == kFormatSrgb[i];
   for (int i = 0; i < 5; ++i)
     fast = fast && (c->tex[i].w & (c->tex[i].w - 1)) == 0 && (c->tex[i].h & (c->tex[i].h - 1)) == 0 && c->tex[i].w == c->tex[0].w &&
@@ -311,11 +320,15 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // The specialised frame has no vertex launch: the setup kernel transforms each triangle's vertices from
   // the streams itself.  The general-sampler resolve reads transformed vertices from memory, so that
   // frame keeps the vertex launch.
-  sky_a.count = fast ? 0 : (int)(n_tiles * share_vertex);
-  sky_b = sky_a; sky_b.first = sky_a.count; sky_b.count = std::min(n_tiles - sky_a.count, (int)(n_tiles * (fast ? share_vertex + share_setup : share_setup)));
+  // The multisampled resolve also reads transformed vertices, and blends over the skybox colour, which
+  // therefore has to be complete before the rasteriser: its tiles are split between the two launches before it.
+  const bool from_streams = fast && !msaa;
+  sky_a.count = from_streams ? 0 : (int)(n_tiles * share_vertex);
+  sky_b = sky_a; sky_b.first = sky_a.count;
+  sky_b.count = msaa ? n_tiles - sky_a.count : std::min(n_tiles - sky_a.count, (int)(n_tiles * (fast ? share_vertex + share_setup : share_setup)));
   const int sky_from_tile = sky_b.first + sky_b.count;
   VertexSource source = {c->d_vout, nullptr, nullptr, nullptr};
-  if (fast) { source.vsoa = c->d_vsoa; source.inst_model = c->d_inst_model; source.inst_normal = c->d_inst_normal; }
+  if (from_streams) { source.vsoa = c->d_vsoa; source.inst_model = c->d_inst_model; source.inst_normal = c->d_inst_normal; }
   else launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances, sky_a);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
   launch_setup_and_bin(s, dp, source, c->d_indices, c->d_setup, c->d_records, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
@@ -325,8 +338,12 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // the visibility buffer is only written when someone will read it: the caller (vis output), the
   // coverage count of the statistics, or the general-sampler resolve
   const bool write_vis = d_vis != nullptr || want_host_vis || timed || !fast;
-  launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
-                counters, next_counters, c->quad_lists, write_vis, pr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
+  if (msaa)
+    launch_raster_msaa(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
+                       counters, next_counters, tiles_x, tiles_y);
+  else
+    launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
+                  counters, next_counters, c->quad_lists, write_vis, pr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
 
   ResolveInputs in;
@@ -336,16 +353,17 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   in.irr_b = pr->irr_b.cube; in.pre_b = pr->pre_b.cube; in.sky_b = pr->sky_b.cube;
   in.lut = c->d_lut; in.lut_size = c->lut_size;
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
-  launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->quad_lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
+  if (msaa) launch_surface_msaa(s, dp, in, pr->d_srgb_lut, vis, color, W, rows, fast);
+  else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->quad_lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
-  c->last_w = W; c->last_rows = rows;
+  c->last_w = W; c->last_rows = rows; c->last_samples = samples;
   ++pr->frames_drawn;
 
   if (timed) {
     HIP_TRY(c, hipMemsetAsync(&counters[3], 0, sizeof(uint32_t), s));
-    launch_count_covered(s, vis, (size_t)W * rows, &counters[3]);
+    launch_count_covered(s, vis, (size_t)W * rows, samples, &counters[3]);
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     (void)hipEventElapsedTime(&stats->ms_vertex, c->ev[0], c->ev[1]);
@@ -746,14 +764,15 @@ int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t 
   DeviceGuard guard(c->device);
   // make sure the internal colour / visibility buffers exist at this size before drawing into them
   const int rows = y1 - y0;
-  int rc = ensure_frame_buffers(c, w, rows, ((w + PBR_TILE - 1) / PBR_TILE) * ((rows + PBR_TILE - 1) / PBR_TILE));
+  const int samples = (u && (u->sampler_index & 16u)) ? 4 : 1;
+  int rc = ensure_frame_buffers(c, w, rows, ((w + PBR_TILE - 1) / PBR_TILE) * ((rows + PBR_TILE - 1) / PBR_TILE), samples);
   if (rc) return rc;
   rc = draw_common(c, u, w, h, y0, y1, c->d_color, nullptr, vis_out != nullptr, stats);
   if (rc) return rc;
   const size_t npix = (size_t)w * rows;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(rgba8_out, c->d_color, npix * 4, hipMemcpyDeviceToHost));
-  if (vis_out) HIP_TRY(c, hipMemcpy(vis_out, c->d_vis, npix * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (vis_out) HIP_TRY(c, hipMemcpy(vis_out, c->d_vis, npix * samples * sizeof(uint32_t), hipMemcpyDeviceToHost));
   HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return check_sticky(c);
 }
@@ -762,7 +781,7 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   if (!c || !u) return PBR_E_ARG;
   if (!c->d_vsoa) return fail(c, PBR_E_STATE, "no mesh uploaded");
   DeviceGuard guard(c->device);
-  int rc = ensure_frame_buffers(c, 32, 32, 1);
+  int rc = ensure_frame_buffers(c, 32, 32, 1, 1);
   if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   FrameParams fp;
@@ -770,6 +789,7 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   mat4_mul_host(u->projection, u->view, fp.pv);
   fp.W = 32; fp.H = 32; fp.y0 = 0; fp.y1 = 32; fp.tiles_x = 1; fp.tiles_y = 1;
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances; fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
+  fp.msaa = 0;
   SkyShare none = {};
   launch_vertex_stage(c->stream, fp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances, none);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -793,7 +813,7 @@ int pbr_debug_capture_depth(PbrContext* c, int32_t enable) {
 int pbr_debug_depth(PbrContext* c, float* depth_out, size_t n_floats) {
   if (!c || !depth_out) return PBR_E_ARG;
   if (!c->capture_depth) return fail(c, PBR_E_STATE, "depth capture is off; call pbr_debug_capture_depth(ctx, 1) before drawing");
-  const size_t n = (size_t)c->last_w * c->last_rows;
+  const size_t n = (size_t)c->last_w * c->last_rows * c->last_samples;
   if (!c->d_depth || n == 0) return fail(c, PBR_E_STATE, "no frame drawn yet");
   if (n_floats < n) return fail(c, PBR_E_ARG, "depth buffer needs %zu floats", n);
   DeviceGuard guard(c->device);

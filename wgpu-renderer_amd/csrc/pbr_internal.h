@@ -93,6 +93,7 @@ struct FrameParams {
   int32_t tiles_x, tiles_y; // tiles covering rows [y0,y1)
   int32_t n_verts, n_tris, n_instances;
   int32_t has_instance_mats;
+  int32_t msaa;             // 1 = four samples per pixel (bit 16 of the sampler index, renderer.ts:1927-1932)
 };
 
 struct PbrContext {
@@ -135,8 +136,8 @@ struct PbrContext {
   uint32_t* d_counters = nullptr; // two sets of 8, used by alternate frames: [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6], [7] uniform and mixed quads
   bool capture_depth = false;
   uint32_t* h_counters = nullptr; // pinned mirror
-  uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0;
-  int32_t last_w = 0, last_rows = 0;
+  uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0, vis_cap = 0;   // vis / depth hold vis_cap entries (one per sample)
+  int32_t last_w = 0, last_rows = 0, last_samples = 1;
   FrameParams* d_params = nullptr;
   FrameParams* h_params = nullptr;   // pinned staging
 
@@ -182,6 +183,13 @@ struct ResolveInputs {
 // covered pixels; the rasteriser has already written the skybox colour of the background pixels
 void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
                     const QuadLists& lists, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks);
+// The multisampled frame: vis (and depth, when wanted) hold four entries per pixel; the colour target already
+// holds the skybox colour of every pixel and the resolve blends the shaded triangles over it by coverage.
+void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
+                        uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, int tiles_x, int tiles_y);
+void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8, int W,
+                         int rows, bool fast);
 int surface_fast_blocks_per_cu();
 void launch_cube_border(hipStream_t s, DevCube src, int level, float4* dst_level);
-void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered);
+// pixels with at least one covered sample
+void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n_pixels, int samples, uint32_t* covered);

@@ -91,9 +91,10 @@ struct TileBox { int tx0, tx1, ty0, ty1; };
 PBR_DEV bool setup_bounds(const SetupTri& t, const FrameParams* p, TileBox& box) {
   const int minX = min(t.X[0], min(t.X[1], t.X[2])), maxX = max(t.X[0], max(t.X[1], t.X[2]));
   const int minY = min(t.Y[0], min(t.Y[1], t.Y[2])), maxY = max(t.Y[0], max(t.Y[1], t.Y[2]));
-  // pixel centres px*256+128 within [min, max]
-  const int minx = max((minX - 128 + 255) >> 8, 0), maxx = min((maxX - 128) >> 8, p->W - 1);
-  const int miny = max((minY - 128 + 255) >> 8, p->y0), maxy = min((maxY - 128) >> 8, p->y1 - 1);
+  // pixel centres px*256+128 within [min, max]; with four samples per pixel, every pixel whose square meets [min, max]
+  const int lo = p->msaa ? 0 : 127, hi = p->msaa ? 0 : 128;
+  const int minx = max((minX + lo) >> 8, 0), maxx = min((maxX - hi) >> 8, p->W - 1);
+  const int miny = max((minY + lo) >> 8, p->y0), maxy = min((maxY - hi) >> 8, p->y1 - 1);
   if (minx > maxx || miny > maxy) return false;
   box.tx0 = minx / PBR_TILE; box.tx1 = maxx / PBR_TILE;
   box.ty0 = (miny - p->y0) / PBR_TILE; box.ty1 = (maxy - p->y0) / PBR_TILE;
@@ -504,6 +505,140 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The rasteriser of the multisampled pipeline (multisample.count = 4, renderer.ts:492-501): the same
+// tile scheme with four keys per pixel, one per sample point of the standard pattern
+// (0.375, 0.125), (0.875, 0.375), (0.125, 0.625), (0.625, 0.875).  Coverage, depth and the depth
+// test are per sample.  It writes four triangle ids per pixel ([y][x][sample]); the resolve that
+// follows shades each triangle of a pixel once and blends by coverage.
+// ---------------------------------------------------------------------------------------------
+__constant__ int kSampleX[4] = {96, 224, 32, 160};   // 1/256 pixel, from the pixel's top-left corner
+__constant__ int kSampleY[4] = {32, 96, 160, 224};
+
+__global__ void __launch_bounds__(256) raster_msaa_kernel(const FrameParams frame_params, const SetupTri* __restrict__ setup,
+                                                          uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
+                                                          const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
+                                                          float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters) {
+  const FrameParams* __restrict__ p = &frame_params;
+  __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE * 4];
+  const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
+  const int px0 = blockIdx.x * PBR_TILE, py0 = p->y0 + blockIdx.y * PBR_TILE;
+  const uint32_t n = tile_count[tile];
+  const uint32_t n_row = min(n, (uint32_t)PBR_BIN_CAP);
+  const uint32_t n_entries = n_row + (n > PBR_BIN_CAP ? min(counters[1], overflow_cap) : 0u);
+  const int xmax = min(px0 + PBR_TILE, p->W) - 1, ymax = min(py0 + PBR_TILE, p->y1) - 1;
+  const unsigned long long clear_key = (unsigned long long)depth_key(1.0f) << 32;
+
+  if (n != 0u) {
+    for (int i = tid; i < PBR_TILE * PBR_TILE * 4; i += 256) s_key[i] = clear_key;
+    __syncthreads();
+    const long long ox = (long long)px0 * 256, oy = (long long)py0 * 256;   // the tile's corner: sample offsets are added per sample
+    for (uint32_t chunk = 0; chunk < n_entries; chunk += 256) {
+      bool keep = false;
+      long long e0 = 0, e1 = 0, e2 = 0;
+      int a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0, tl = 0, box = 0;
+      float z0 = 0, dz1 = 0, dz2 = 0, inv_area = 0;
+      uint32_t id = 0;
+      const uint32_t entry = chunk + 4u * lane + wave;
+      uint32_t slot = 0xffffffffu;
+      if (entry < n_row) slot = bins[(size_t)tile * PBR_BIN_CAP + entry];
+      else if (entry < n_entries) { const uint2 pr = overflow[entry - n_row]; if (pr.x == (uint32_t)tile) slot = pr.y; }
+      if (slot != 0xffffffffu) {
+        const SetupTri t = setup[slot];
+        keep = true;
+        long long e[3]; int a[3], b[3];
+        bool narrow = true;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int ia = (k + 1) % 3, ib = (k + 2) % 3;
+          const int dx = t.X[ib] - t.X[ia], dy = t.Y[ib] - t.Y[ia];
+          a[k] = -dy; b[k] = dx;
+          e[k] = (long long)dx * (oy - t.Y[ia]) - (long long)dy * (ox - t.X[ia]);
+          if (dy < 0 || (dy == 0 && dx > 0)) tl |= 1 << k;
+          // an upper bound of the edge function over the tile's sample points (which lie inside the pixel squares)
+          const long long ex = a[k] > 0 ? (long long)a[k] * ((xmax - px0 + 1) * 256) : 0;
+          const long long ey = b[k] > 0 ? (long long)b[k] * ((ymax - py0 + 1) * 256) : 0;
+          if (e[k] + ex + ey < 0) keep = false;
+          const long long reach = (long long)(abs(a[k]) + abs(b[k])) * (PBR_TILE * 256);
+          const long long mag = e[k] < 0 ? -e[k] : e[k];
+          narrow = narrow && abs(a[k]) < (1 << 23) && abs(b[k]) < (1 << 23) && mag + reach < (1ll << 31) - 1;
+        }
+        e0 = e[0]; e1 = e[1]; e2 = e[2]; a0 = a[0]; a1 = a[1]; a2 = a[2]; b0 = b[0]; b1 = b[1]; b2 = b[2];
+        z0 = t.z0; dz1 = t.dz1; dz2 = t.dz2; inv_area = t.inv_area; id = t.id;
+        const int minX = min(t.X[0], min(t.X[1], t.X[2])), maxX = max(t.X[0], max(t.X[1], t.X[2]));
+        const int minY = min(t.Y[0], min(t.Y[1], t.Y[2])), maxY = max(t.Y[0], max(t.Y[1], t.Y[2]));
+        const int bx0 = max(minX >> 8, px0) - px0, bx1 = min(maxX >> 8, xmax) - px0;
+        const int by0 = max(minY >> 8, py0) - py0, by1 = min(maxY >> 8, ymax) - py0;
+        if (bx0 > bx1 || by0 > by1) keep = false;
+        box = bx0 | (bx1 << 8) | (by0 << 16) | (by1 << 24);
+        if (narrow) tl |= 8;
+      }
+      unsigned long long todo = __ballot(keep);
+      const int lx = lane & 7, ly = lane >> 3;
+      while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long long E0 = bcast64(e0, src), E1 = bcast64(e1, src), E2 = bcast64(e2, src);
+        const int A0 = bcast(a0, src), A1 = bcast(a1, src), A2 = bcast(a2, src), B0 = bcast(b0, src), B1 = bcast(b1, src), B2 = bcast(b2, src);
+        const int TL = bcast(tl, src), BOX = bcast(box, src);
+        const float Z0 = __int_as_float(bcast(__float_as_int(z0), src)), DZ1 = __int_as_float(bcast(__float_as_int(dz1), src)),
+                    DZ2 = __int_as_float(bcast(__float_as_int(dz2), src)), IA = __int_as_float(bcast(__float_as_int(inv_area), src));
+        const uint32_t ID = (uint32_t)bcast((int)id, src) + 1u;
+        const int bx0 = BOX & 255, bx1 = (BOX >> 8) & 255, by0 = (BOX >> 16) & 255, by1 = (BOX >> 24) & 255;
+        const int c0 = (TL & 1) ? 0 : -1, c1 = (TL & 2) ? 0 : -1, c2 = (TL & 4) ? 0 : -1;   // e > 0, or e >= 0 on top-left edges
+        for (int yy = by0; yy <= by1; yy += 8)
+          for (int xx = bx0; xx <= bx1; xx += 8) {
+            const int x = xx + lx, y = yy + ly;
+            if (x > bx1 || y > by1) continue;
+#pragma unroll
+            for (int sm = 0; sm < 4; ++sm) {
+              const int xs = x * 256 + kSampleX[sm], ys = y * 256 + kSampleY[sm];
+              float fl1, fl2;
+              if (TL & 8) {   // 32-bit edge functions with 24-bit multiplies are exact for this triangle over this tile
+                const int f0 = (int)E0 + __mul24(A0, xs) + __mul24(B0, ys);
+                const int f1 = (int)E1 + __mul24(A1, xs) + __mul24(B1, ys);
+                const int f2 = (int)E2 + __mul24(A2, xs) + __mul24(B2, ys);
+                if (((f0 + c0) | (f1 + c1) | (f2 + c2)) < 0) continue;
+                fl1 = (float)f1; fl2 = (float)f2;
+              } else {
+                const long long f0 = E0 + (long long)A0 * xs + (long long)B0 * ys;
+                const long long f1 = E1 + (long long)A1 * xs + (long long)B1 * ys;
+                const long long f2 = E2 + (long long)A2 * xs + (long long)B2 * ys;
+                if (((f0 + c0) | (f1 + c1) | (f2 + c2)) < 0) continue;
+                fl1 = (float)f1; fl2 = (float)f2;
+              }
+              const float l1 = mul_rn(fl1, IA), l2 = mul_rn(fl2, IA);
+              const float z = add_rn(add_rn(Z0, mul_rn(l1, DZ1)), mul_rn(l2, DZ2));
+              atomicMin(&s_key[(y * PBR_TILE + x) * 4 + sm], ((unsigned long long)depth_key(z) << 32) | ID);
+            }
+          }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) tile_count[tile] = 0u;   // leave the bin counters clear for the next frame
+
+  // write the tile out: thread t holds pixels 4t .. 4t+3 of the row-major tile, four samples each
+  const int ty = tid >> 3, tx = (tid & 7) * 4;
+  const int y = py0 + ty, x = px0 + tx;
+  if (y > ymax || x > xmax) return;
+  const size_t o = ((size_t)(y - p->y0) * p->W + x) * 4;
+  for (int k = 0; k < 4 && x + k <= xmax; ++k) {
+    uint4 ids = make_uint4(0u, 0u, 0u, 0u);
+    float4 zs = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+    if (n != 0u) {
+      const unsigned long long* key = &s_key[(ty * PBR_TILE + tx + k) * 4];
+      ids = make_uint4((uint32_t)key[0], (uint32_t)key[1], (uint32_t)key[2], (uint32_t)key[3]);
+      zs = make_float4(key_depth((uint32_t)(key[0] >> 32)), key_depth((uint32_t)(key[1] >> 32)), key_depth((uint32_t)(key[2] >> 32)),
+                       key_depth((uint32_t)(key[3] >> 32)));
+    }
+    *reinterpret_cast<uint4*>(vis + o + 4 * k) = ids;
+    if (depth) *reinterpret_cast<float4*>(depth + o + 4 * k) = zs;
+  }
+}
+
 }  // namespace
 
 void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa, const float* inst_model, const float* inst_normal,
@@ -535,4 +670,10 @@ void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, u
                    const DevCube& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y) {
   hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
                      next_counters, lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile);
+}
+
+void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
+                        uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, int tiles_x, int tiles_y) {
+  hipLaunchKernelGGL(raster_msaa_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
+                     next_counters);
 }

@@ -432,32 +432,20 @@ PBR_DEV uint32_t shade_owned(const FrameParams* p, const ResolveInputs& in, cons
 
 PBR_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src)); }
 
-// One thread per covered pixel.  Lanes 4q..4q+3 of a wavefront are the pixels (0,0), (1,0), (0,1),
-// (1,1) of quad q; a wavefront covers 32 x 2 pixels, a workgroup 32 x 8.
+// fs_main for the lane's pixel of quad (qx, qy) on triangle id - 1 (0 = nothing to shade).  Lanes 4q..4q+3 of
+// a wavefront are the pixels (0,0), (1,0), (0,1), (1,1) of one quad; every lane of the wavefront must make the
+// call (the lanes of a quad exchange helper results).  A lane whose three helper pixels show the same triangle
+// borrows their results; otherwise it evaluates its own triangle at those pixels itself.
 template <bool FAST>
-__global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams frame_params, ResolveInputs in, const float* __restrict__ srgb_lut,
-                                                              const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8) {
-  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
-  __shared__ float s_srgb[256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & 3, quad = lane >> 2;
-  const int qx = blockIdx.x * 32 + quad * 2, qy = p->y0 + blockIdx.y * 8 + wave * 2;
-  const int x = qx + (sub & 1), y = qy + (sub >> 1);
-  const bool live = x < p->W && y < p->y1;
-  const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
-  const uint32_t id = live ? vis[o] : 0u;
-  if (__syncthreads_or(id != 0u) == 0) return;   // nothing but background in this workgroup
-  s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
-  __syncthreads();
-  if (__ballot(id != 0u) == 0ull) return;
+PBR_DEV uint32_t shade_quad_lane(const FrameParams* p, const ResolveInputs& in, const float* s_srgb, uint32_t id, int qx, int qy, int lane) {
   // ids of the quad's pixels (0,0), (1,0), (0,1): helper results can be borrowed from a lane that shows the same triangle
   const int qbase = lane & ~3;
   const uint32_t id0 = __shfl(id, qbase), id1 = __shfl(id, qbase + 1), id2 = __shfl(id, qbase + 2);
   const bool share0 = id0 == id, share1 = id1 == id, share2 = id2 == id;
   const bool need_explicit = id != 0u && !(share0 && share1 && share2);
-  const bool any_explicit = __any(need_explicit);
 
   uint32_t color = 0;
+  const int sub = lane & 3;
   Varyings f;
   Eval fc;
   QuadShared q;
@@ -504,7 +492,6 @@ __global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams 
       lut0 = make_float2(e0.ndotv, e0.roughness); lut1 = make_float2(e1.ndotv, e1.roughness); lut2 = make_float2(e2.ndotv, e2.roughness);
     }
   }
-  (void)any_explicit;
   // borrow the helper results of uniform quads from the neighbouring lanes (all lanes take part in the exchange)
   {
     const V3 s0 = shfl3(fc.R, qbase), s1 = shfl3(fc.R, qbase + 1), s2 = shfl3(fc.R, qbase + 2);
@@ -515,8 +502,74 @@ __global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams 
   if (id != 0u) {
     const float lambda = cube_lambda(in.pre.size, fc.R, R1 - R0, R2 - R0);   // implicit LOD of shader.wgsl:149
     color = shade_owned<FAST>(p, in, q, f, fc, fp, lambda, make_float2(lut1.x - lut0.x, lut1.y - lut0.y), make_float2(lut2.x - lut0.x, lut2.y - lut0.y), s_srgb);
-    rgba8[o] = color;
   }
+  return color;
+}
+
+// One thread per covered pixel; a wavefront covers 32 x 2 pixels, a workgroup 32 x 8.
+template <bool FAST>
+__global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams frame_params, ResolveInputs in, const float* __restrict__ srgb_lut,
+                                                              const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8) {
+  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
+  __shared__ float s_srgb[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 3, quad = lane >> 2;
+  const int qx = blockIdx.x * 32 + quad * 2, qy = p->y0 + blockIdx.y * 8 + wave * 2;
+  const int x = qx + (sub & 1), y = qy + (sub >> 1);
+  const bool live = x < p->W && y < p->y1;
+  const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
+  const uint32_t id = live ? vis[o] : 0u;
+  if (__syncthreads_or(id != 0u) == 0) return;   // nothing but background in this workgroup
+  s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
+  __syncthreads();
+  if (__ballot(id != 0u) == 0ull) return;
+  const uint32_t color = shade_quad_lane<FAST>(p, in, s_srgb, id, qx, qy, lane);
+  if (id != 0u) rgba8[o] = color;
+}
+
+// The resolve of the multisampled pipeline.  vis holds the triangle of each of the pixel's four samples.
+// Each distinct triangle of a pixel is shaded once, at the pixel centre, and its 8-bit colour counts once
+// per sample it owns; samples without a triangle count the skybox colour the pixel already holds; the
+// pixel becomes the average of the four, rounded half to even.
+template <bool FAST>
+__global__ void __launch_bounds__(256) resolve_surface_msaa_kernel(const FrameParams frame_params, ResolveInputs in, const float* __restrict__ srgb_lut,
+                                                                   const uint4* __restrict__ vis, uint32_t* __restrict__ rgba8) {
+  const FrameParams* __restrict__ p = &frame_params;
+  __shared__ float s_srgb[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 3, quad = lane >> 2;
+  const int qx = blockIdx.x * 32 + quad * 2, qy = p->y0 + blockIdx.y * 8 + wave * 2;
+  const int x = qx + (sub & 1), y = qy + (sub >> 1);
+  const bool live = x < p->W && y < p->y1;
+  const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
+  const uint4 ids = live ? vis[o] : make_uint4(0u, 0u, 0u, 0u);
+  const bool any = (ids.x | ids.y | ids.z | ids.w) != 0u;
+  if (__syncthreads_or(any) == 0) return;
+  s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
+  __syncthreads();
+  if (__ballot(any) == 0ull) return;
+  uint32_t sum_r = 0, sum_g = 0, sum_b = 0, covered = 0;
+#pragma unroll 1
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t idk = k == 0 ? ids.x : k == 1 ? ids.y : k == 2 ? ids.z : ids.w;
+    // shade on the first sample that shows a triangle; later samples of the same triangle only add to its weight
+    const bool first = idk != 0u && !(k > 0 && ids.x == idk) && !(k > 1 && ids.y == idk) && !(k > 2 && ids.z == idk);
+    const uint32_t cur = first ? idk : 0u;
+    if (__ballot(cur != 0u) == 0ull) continue;   // the same decision in every lane
+    const uint32_t c = shade_quad_lane<FAST>(p, in, s_srgb, cur, qx, qy, lane);
+    if (cur != 0u) {
+      const uint32_t count = (uint32_t)(ids.x == cur) + (uint32_t)(ids.y == cur) + (uint32_t)(ids.z == cur) + (uint32_t)(ids.w == cur);
+      sum_r += count * (c & 255u); sum_g += count * ((c >> 8) & 255u); sum_b += count * ((c >> 16) & 255u);
+      covered += count;
+    }
+  }
+  if (!any) return;
+  if (covered < 4u) {
+    const uint32_t sky = rgba8[o], count = 4u - covered;
+    sum_r += count * (sky & 255u); sum_g += count * ((sky >> 8) & 255u); sum_b += count * ((sky >> 16) & 255u);
+  }
+  auto quarter = [](uint32_t v) { const uint32_t q = v >> 2, rem = v & 3u; return q + (uint32_t)(rem > 2u || (rem == 2u && (q & 1u))); };
+  rgba8[o] = quarter(sum_r) | (quarter(sum_g) << 8) | (quarter(sum_b) << 16) | 0xff000000u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -798,11 +851,14 @@ __global__ void __launch_bounds__(256) cube_border_kernel(DevCube src, int level
 
 // Number of covered pixels, for the frame statistics only: one atomic per 16384 pixels (a single
 // counter sustains under a hundred atomics per microsecond, so it must not sit in the resolve).
-__global__ void __launch_bounds__(256) count_covered_kernel(const uint32_t* __restrict__ vis, size_t n, uint32_t* __restrict__ covered) {
+__global__ void __launch_bounds__(256) count_covered_kernel(const uint32_t* __restrict__ vis, size_t n, int samples, uint32_t* __restrict__ covered) {
   __shared__ uint32_t s_part[4];
   uint32_t c = 0;
   const size_t begin = (size_t)blockIdx.x * 16384;
-  for (size_t i = begin + threadIdx.x; i < begin + 16384 && i < n; i += 256) c += vis[i] != 0u;
+  for (size_t i = begin + threadIdx.x; i < begin + 16384 && i < n; i += 256) {
+    if (samples == 4) { const uint4 v = reinterpret_cast<const uint4*>(vis)[i]; c += (v.x | v.y | v.z | v.w) != 0u; }
+    else c += vis[i] != 0u;
+  }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = c;
@@ -831,11 +887,20 @@ void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in
   }
 }
 
+void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8, int W,
+                         int rows, bool fast) {
+  dim3 grid((W + 31) / 32, (rows + 7) / 8);
+  const uint4* vis4 = reinterpret_cast<const uint4*>(vis);
+  uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
+  if (fast) hipLaunchKernelGGL(resolve_surface_msaa_kernel<true>, grid, dim3(256), 0, s, p, in, srgb_lut, vis4, out);
+  else hipLaunchKernelGGL(resolve_surface_msaa_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis4, out);
+}
+
 void launch_cube_border(hipStream_t s, DevCube src, int level, float4* dst_level) {
   const int n = std::max(1, src.size >> level), m = n + 2;
   hipLaunchKernelGGL(cube_border_kernel, dim3((unsigned)((6u * m * m + 255u) / 256u)), dim3(256), 0, s, src, level, dst_level);
 }
 
-void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, uint32_t* covered) {
-  hipLaunchKernelGGL(count_covered_kernel, dim3((unsigned)((n + 16383) / 16384)), dim3(256), 0, s, vis, n, covered);
+void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, int samples, uint32_t* covered) {
+  hipLaunchKernelGGL(count_covered_kernel, dim3((unsigned)((n + 16383) / 16384)), dim3(256), 0, s, vis, n, samples, covered);
 }

@@ -245,9 +245,10 @@ napi_value DrawFrame(napi_env env, napi_callback_info info) {
   if (ulen != sizeof(PbrFrameUniforms)) { napi_throw_range_error(env, nullptr, "uniforms must be sizeof(PbrFrameUniforms) = 496 bytes"); return nullptr; }
   if (w <= 0 || h <= 0 || y0 < 0 || y1 <= y0 || y1 > h) { napi_throw_range_error(env, nullptr, "bad frame size or row range"); return nullptr; }
   const size_t px = (size_t)w * (size_t)(y1 - y0);
-  if (olen != px * 4 || (vis && vlen != px)) { napi_throw_range_error(env, nullptr, "output arrays do not match the row range"); return nullptr; }
   PbrFrameUniforms uniforms;
   std::memcpy(&uniforms, u, sizeof(uniforms));
+  const size_t samples = (uniforms.sampler_index & 16u) ? 4 : 1;   // the multisampled pipeline reports one id per sample
+  if (olen != px * 4 || (vis && vlen != px * samples)) { napi_throw_range_error(env, nullptr, "output arrays do not match the row range"); return nullptr; }
   PbrFrameStats st;
   if (!check(env, ctx, pbr_draw_frame(ctx, &uniforms, w, h, y0, y1, static_cast<uint8_t*>(out), static_cast<uint32_t*>(vis), want_stats ? &st : nullptr)))
     return nullptr;

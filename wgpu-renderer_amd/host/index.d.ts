@@ -52,6 +52,7 @@ export type FrameStats = {
   coveredPixels: number; spilledRefs: number; setupTriangles: number; uniformQuads: number; mixedQuads: number;
 };
 
+/** vis: triangle id + 1 per pixel (0 = skybox); four per pixel, in sample order, when msaaOptions.enable is set */
 export type Frame = { rgba: Uint8Array; vis?: Uint32Array; stats: FrameStats };
 
 export type RendererOptions = {

@@ -149,7 +149,8 @@ class Renderer {
     const rows = y1 - y0;
     const uniforms = this.frameUniforms();
     const rgba = new Uint8Array(this.width * rows * 4);
-    const vis = options.wantVis ? new Uint32Array(this.width * rows) : null;
+    // one triangle id per pixel, or one per sample when multisampling is on
+    const vis = options.wantVis ? new Uint32Array(this.width * rows * (this.msaaOptions.enable ? 4 : 1)) : null;
     const stats = addon.drawFrame(this.ctx, new Uint8Array(uniforms.buffer), this.width, this.height, y0, y1, rgba, vis, true);
     this.pixels = rgba;
     this.frameTime = stats.msTotal;

@@ -167,7 +167,9 @@ class Renderer:
         u = self.frame_uniforms()
         rows = y1 - y0
         rgba = np.empty((rows, self.width, 4), dtype=np.uint8)
-        vis = np.empty((rows, self.width), dtype=np.uint32) if want_vis else None
+        # one triangle id per pixel, or one per sample with multisampling on
+        vis_shape = (rows, self.width, 4) if u.sampler_index & 16 else (rows, self.width)
+        vis = np.empty(vis_shape, dtype=np.uint32) if want_vis else None
         stats = _lib.FrameStats() if want_stats else None
         self._check(self._lib.pbr_draw_frame(self._ctx, C.byref(u), self.width, self.height, y0, y1, _fptr(rgba),
                                              _fptr(vis) if want_vis else None, C.byref(stats) if want_stats else None))
