@@ -200,14 +200,17 @@ def test_multisampled_pipeline_matches_oracle(small, sampler_index, moves):
         _, odepth = small.oracle.raster(small.uniforms(), small.width, small.height)
         assert (depth.view(np.uint32) == odepth.view(np.uint32)).all()
         assert stats.covered_pixels == int((vis != 0).any(-1).sum())
-        # a pixel whose four samples show the triangle of the single-sample frame keeps that frame's colour (to the
-        # last bit when both frames go through the same resolve kernel; the default sampler's single-sample frame
-        # has a specialised one); silhouette pixels are blends and differ
+        # a pixel whose four samples show the triangle of the single-sample frame keeps that frame's colour (the two
+        # frames go through different kernels, so a value on a rounding boundary may land on either side);
+        # silhouette pixels are blends and differ
         same = (vis == vis1[..., None]).all(-1)
         dsame = np.abs(rgba[same].astype(np.int32) - single[same].astype(np.int32))
-        assert dsame.max() <= (1 if sampler_index == 15 else 0) and (dsame > 0).mean() < 1e-3
+        assert dsame.max() <= 1 and (dsame > 0).mean() < 1e-3, (dsame.max(), (dsame > 0).mean())
         edge = ~same
         assert 0.002 < edge.mean() < 0.2 and (rgba[edge] != single[edge]).any()
+        # a frame drawn for its colour alone leaves the entries of empty tiles unwritten: same picture
+        lib.check(r._ctx, r._lib.pbr_debug_capture_depth(r._ctx, 0))
+        assert (r.draw_frame() == rgba).all()
         # strips compose to the full frame in this mode too
         top, vtop = small.render_gpu(0, 100)
         bottom, vbottom = small.render_gpu(100, small.height)

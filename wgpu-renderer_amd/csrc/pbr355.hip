@@ -167,12 +167,13 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int sample
   }
   if ((size_t)n_tiles > c->tile_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
+    free_dev(c->d_tile_count); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
     const size_t n_quads = (size_t)n_tiles * (PBR_TILE / 2) * (PBR_TILE / 2);
     HIP_TRY(c, hipMalloc(&c->quad_lists.uniform, sizeof(uint2) * n_quads));
     HIP_TRY(c, hipMalloc(&c->quad_lists.mixed_pos, sizeof(uint32_t) * n_quads));
     HIP_TRY(c, hipMalloc(&c->quad_lists.mixed_ids, sizeof(uint4) * n_quads));
     HIP_TRY(c, hipMalloc(&c->d_tile_count, sizeof(uint32_t) * n_tiles));
+    HIP_TRY(c, hipMalloc(&c->d_tile_live, sizeof(uint32_t) * n_tiles));
     HIP_TRY(c, hipMalloc(&c->d_bins, sizeof(uint32_t) * (size_t)n_tiles * PBR_BIN_CAP));
     HIP_TRY(c, hipMemset(c->d_tile_count, 0, sizeof(uint32_t) * n_tiles));   // kept clear from frame to frame by the raster kernel
     c->tile_cap = n_tiles; grew = true;
@@ -337,10 +338,10 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
   // the visibility buffer is only written when someone will read it: the caller (vis output), the
   // coverage count of the statistics, or the general-sampler resolve
-  const bool write_vis = d_vis != nullptr || want_host_vis || timed || !fast;
+  const bool write_vis = d_vis != nullptr || want_host_vis || timed || (!fast && !msaa);
   if (msaa)
     launch_raster_msaa(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
-                       counters, next_counters, tiles_x, tiles_y);
+                       counters, next_counters, c->d_tile_live, write_vis || c->capture_depth, tiles_x, tiles_y);
   else
     launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
                   counters, next_counters, c->quad_lists, write_vis, pr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
@@ -353,7 +354,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   in.irr_b = pr->irr_b.cube; in.pre_b = pr->pre_b.cube; in.sky_b = pr->sky_b.cube;
   in.lut = c->d_lut; in.lut_size = c->lut_size;
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
-  if (msaa) launch_surface_msaa(s, dp, in, pr->d_srgb_lut, vis, color, W, rows, fast);
+  if (msaa) launch_surface_msaa(s, dp, in, pr->d_srgb_lut, vis, c->d_tile_live, color, W, rows, fast);
   else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->quad_lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
@@ -439,7 +440,7 @@ int pbr_destroy(PbrContext* c) {
   free_dev(c->d_hdr); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
   { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); }
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
-  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
+  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
   free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
   free_dev(pr->d_srgb_lut);
   if (c->h_counters) (void)hipHostFree(c->h_counters);

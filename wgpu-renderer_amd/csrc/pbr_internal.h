@@ -130,7 +130,7 @@ struct PbrContext {
   VertexOut* d_vout = nullptr;    size_t vout_cap = 0;
   SetupTri* d_setup = nullptr;    size_t setup_cap = 0;
   TriRecord* d_records = nullptr; size_t record_cap = 0;   // one per triangle of every instance
-  uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0;   // [tiles], [tiles][PBR_BIN_CAP]
+  uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0; uint32_t* d_tile_live = nullptr;   // [tiles], [tiles][PBR_BIN_CAP]
   QuadLists quad_lists = {nullptr, nullptr, nullptr};                                  // work lists of the resolve, each [tiles * 256]
   uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
   uint32_t* d_counters = nullptr; // two sets of 8, used by alternate frames: [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6], [7] uniform and mixed quads
@@ -186,9 +186,10 @@ void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in
 // The multisampled frame: vis (and depth, when wanted) hold four entries per pixel; the colour target already
 // holds the skybox colour of every pixel and the resolve blends the shaded triangles over it by coverage.
 void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                        uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, int tiles_x, int tiles_y);
-void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8, int W,
-                         int rows, bool fast);
+                        uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, uint32_t* tile_live,
+                        bool write_empty_tiles, int tiles_x, int tiles_y);
+void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, const uint32_t* tile_live,
+                         uint8_t* rgba8, int W, int rows, bool fast);
 int surface_fast_blocks_per_cu();
 void launch_cube_border(hipStream_t s, DevCube src, int level, float4* dst_level);
 // pixels with at least one covered sample

@@ -518,7 +518,8 @@ __constant__ int kSampleY[4] = {32, 96, 160, 224};
 __global__ void __launch_bounds__(256) raster_msaa_kernel(const FrameParams frame_params, const SetupTri* __restrict__ setup,
                                                           uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
                                                           const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
-                                                          float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters) {
+                                                          float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters,
+                                                          uint32_t* __restrict__ tile_live, int write_empty) {
   const FrameParams* __restrict__ p = &frame_params;
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE * 4];
   const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
@@ -576,7 +577,9 @@ __global__ void __launch_bounds__(256) raster_msaa_kernel(const FrameParams fram
         if (narrow) tl |= 8;
       }
       unsigned long long todo = __ballot(keep);
-      const int lx = lane & 7, ly = lane >> 3;
+      // a lane is one sample of one pixel: the wavefront sweeps the bounding box in 4 x 4 pixel blocks
+      const int sm = lane & 3, lx = (lane >> 2) & 3, ly = lane >> 4;
+      const int sx = kSampleX[sm], sy = kSampleY[sm];
       while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -588,37 +591,45 @@ __global__ void __launch_bounds__(256) raster_msaa_kernel(const FrameParams fram
         const uint32_t ID = (uint32_t)bcast((int)id, src) + 1u;
         const int bx0 = BOX & 255, bx1 = (BOX >> 8) & 255, by0 = (BOX >> 16) & 255, by1 = (BOX >> 24) & 255;
         const int c0 = (TL & 1) ? 0 : -1, c1 = (TL & 2) ? 0 : -1, c2 = (TL & 4) ? 0 : -1;   // e > 0, or e >= 0 on top-left edges
-        for (int yy = by0; yy <= by1; yy += 8)
-          for (int xx = bx0; xx <= bx1; xx += 8) {
-            const int x = xx + lx, y = yy + ly;
-            if (x > bx1 || y > by1) continue;
-#pragma unroll
-            for (int sm = 0; sm < 4; ++sm) {
-              const int xs = x * 256 + kSampleX[sm], ys = y * 256 + kSampleY[sm];
-              float fl1, fl2;
-              if (TL & 8) {   // 32-bit edge functions with 24-bit multiplies are exact for this triangle over this tile
-                const int f0 = (int)E0 + __mul24(A0, xs) + __mul24(B0, ys);
-                const int f1 = (int)E1 + __mul24(A1, xs) + __mul24(B1, ys);
-                const int f2 = (int)E2 + __mul24(A2, xs) + __mul24(B2, ys);
-                if (((f0 + c0) | (f1 + c1) | (f2 + c2)) < 0) continue;
-                fl1 = (float)f1; fl2 = (float)f2;
-              } else {
-                const long long f0 = E0 + (long long)A0 * xs + (long long)B0 * ys;
-                const long long f1 = E1 + (long long)A1 * xs + (long long)B1 * ys;
-                const long long f2 = E2 + (long long)A2 * xs + (long long)B2 * ys;
-                if (((f0 + c0) | (f1 + c1) | (f2 + c2)) < 0) continue;
-                fl1 = (float)f1; fl2 = (float)f2;
-              }
-              const float l1 = mul_rn(fl1, IA), l2 = mul_rn(fl2, IA);
+        if (TL & 8) {
+          // 32-bit edge functions with 24-bit multiplies are exact for this triangle over this tile
+          const int e0n = (int)E0 + c0 + __mul24(A0, sx) + __mul24(B0, sy), e1n = (int)E1 + __mul24(A1, sx) + __mul24(B1, sy),
+                    e2n = (int)E2 + __mul24(A2, sx) + __mul24(B2, sy);
+          for (int yy = by0; yy <= by1; yy += 4)
+            for (int xx = bx0; xx <= bx1; xx += 4) {
+              const int x = xx + lx, y = yy + ly;
+              if (x > bx1 || y > by1) continue;
+              const int xs = x * 256, ys = y * 256;
+              const int f0 = e0n + __mul24(A0, xs) + __mul24(B0, ys);
+              const int f1 = e1n + __mul24(A1, xs) + __mul24(B1, ys);
+              const int f2 = e2n + __mul24(A2, xs) + __mul24(B2, ys);
+              if ((f0 | (f1 + c1) | (f2 + c2)) < 0) continue;
+              const float l1 = mul_rn((float)f1, IA), l2 = mul_rn((float)f2, IA);
               const float z = add_rn(add_rn(Z0, mul_rn(l1, DZ1)), mul_rn(l2, DZ2));
               atomicMin(&s_key[(y * PBR_TILE + x) * 4 + sm], ((unsigned long long)depth_key(z) << 32) | ID);
             }
-          }
+        } else {
+          for (int yy = by0; yy <= by1; yy += 4)
+            for (int xx = bx0; xx <= bx1; xx += 4) {
+              const int x = xx + lx, y = yy + ly;
+              if (x > bx1 || y > by1) continue;
+              const int xs = x * 256 + sx, ys = y * 256 + sy;
+              const long long f0 = E0 + (long long)A0 * xs + (long long)B0 * ys;
+              const long long f1 = E1 + (long long)A1 * xs + (long long)B1 * ys;
+              const long long f2 = E2 + (long long)A2 * xs + (long long)B2 * ys;
+              if (((f0 + c0) | (f1 + c1) | (f2 + c2)) < 0) continue;
+              const float l1 = mul_rn((float)f1, IA), l2 = mul_rn((float)f2, IA);
+              const float z = add_rn(add_rn(Z0, mul_rn(l1, DZ1)), mul_rn(l2, DZ2));
+              atomicMin(&s_key[(y * PBR_TILE + x) * 4 + sm], ((unsigned long long)depth_key(z) << 32) | ID);
+            }
+        }
       }
     }
     __syncthreads();
   }
-  if (tid == 0) tile_count[tile] = 0u;   // leave the bin counters clear for the next frame
+  if (tid == 0) { tile_count[tile] = 0u; tile_live[tile] = n; }   // leave the bin counters clear for the next frame
+  // The resolve skips tiles that no triangle was binned to, so their entries are only written when the caller reads them.
+  if (n == 0u && !write_empty) return;
 
   // write the tile out: thread t holds pixels 4t .. 4t+3 of the row-major tile, four samples each
   const int ty = tid >> 3, tx = (tid & 7) * 4;
@@ -673,7 +684,8 @@ void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, u
 }
 
 void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
-                        uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, int tiles_x, int tiles_y) {
+                        uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, uint32_t* tile_live,
+                        bool write_empty_tiles, int tiles_x, int tiles_y) {
   hipLaunchKernelGGL(raster_msaa_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
-                     next_counters);
+                     next_counters, tile_live, write_empty_tiles ? 1 : 0);
 }

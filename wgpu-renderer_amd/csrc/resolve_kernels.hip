@@ -432,20 +432,22 @@ PBR_DEV uint32_t shade_owned(const FrameParams* p, const ResolveInputs& in, cons
 
 PBR_DEV V3 shfl3(V3 v, int src) { return v3(__shfl(v.x, src), __shfl(v.y, src), __shfl(v.z, src)); }
 
-// fs_main for the lane's pixel of quad (qx, qy) on triangle id - 1 (0 = nothing to shade).  Lanes 4q..4q+3 of
-// a wavefront are the pixels (0,0), (1,0), (0,1), (1,1) of one quad; every lane of the wavefront must make the
-// call (the lanes of a quad exchange helper results).  A lane whose three helper pixels show the same triangle
-// borrows their results; otherwise it evaluates its own triangle at those pixels itself.
-template <bool FAST>
-PBR_DEV uint32_t shade_quad_lane(const FrameParams* p, const ResolveInputs& in, const float* s_srgb, uint32_t id, int qx, int qy, int lane) {
+// fs_main for pixel `sub` (0..3: (0,0), (1,0), (0,1), (1,1)) of quad (qx, qy) on triangle id - 1 (0 = nothing to
+// shade).  With ALONE unset, lanes 4q..4q+3 of a wavefront are the four pixels of one quad in that order and
+// every lane of the wavefront must make the call: a lane whose three helper pixels show the same triangle
+// borrows their results.  Otherwise (and always with ALONE set, where lanes are unrelated work items) the
+// lane evaluates its own triangle at the helper pixels itself.
+template <bool FAST, bool ALONE>
+PBR_DEV uint32_t shade_quad_lane(const FrameParams* p, const ResolveInputs& in, const float* s_srgb, uint32_t id, int qx, int qy, int lane, int sub) {
   // ids of the quad's pixels (0,0), (1,0), (0,1): helper results can be borrowed from a lane that shows the same triangle
   const int qbase = lane & ~3;
-  const uint32_t id0 = __shfl(id, qbase), id1 = __shfl(id, qbase + 1), id2 = __shfl(id, qbase + 2);
-  const bool share0 = id0 == id, share1 = id1 == id, share2 = id2 == id;
-  const bool need_explicit = id != 0u && !(share0 && share1 && share2);
+  bool need_explicit = id != 0u;
+  if constexpr (!ALONE) {
+    const uint32_t id0 = __shfl(id, qbase), id1 = __shfl(id, qbase + 1), id2 = __shfl(id, qbase + 2);
+    need_explicit = id != 0u && !(id0 == id && id1 == id && id2 == id);
+  }
 
   uint32_t color = 0;
-  const int sub = lane & 3;
   Varyings f;
   Eval fc;
   QuadShared q;
@@ -493,7 +495,7 @@ PBR_DEV uint32_t shade_quad_lane(const FrameParams* p, const ResolveInputs& in, 
     }
   }
   // borrow the helper results of uniform quads from the neighbouring lanes (all lanes take part in the exchange)
-  {
+  if constexpr (!ALONE) {
     const V3 s0 = shfl3(fc.R, qbase), s1 = shfl3(fc.R, qbase + 1), s2 = shfl3(fc.R, qbase + 2);
     const float n0 = __shfl(fc.ndotv, qbase), n1 = __shfl(fc.ndotv, qbase + 1), n2 = __shfl(fc.ndotv, qbase + 2);
     const float r0 = __shfl(fc.roughness, qbase), r1 = __shfl(fc.roughness, qbase + 1), r2 = __shfl(fc.roughness, qbase + 2);
@@ -523,7 +525,7 @@ __global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams 
   s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
   __syncthreads();
   if (__ballot(id != 0u) == 0ull) return;
-  const uint32_t color = shade_quad_lane<FAST>(p, in, s_srgb, id, qx, qy, lane);
+  const uint32_t color = shade_quad_lane<FAST, false>(p, in, s_srgb, id, qx, qy, lane, sub);
   if (id != 0u) rgba8[o] = color;
 }
 
@@ -531,11 +533,21 @@ __global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams 
 // Each distinct triangle of a pixel is shaded once, at the pixel centre, and its 8-bit colour counts once
 // per sample it owns; samples without a triangle count the skybox colour the pixel already holds; the
 // pixel becomes the average of the four, rounded half to even.
+// The triangle of sample 0 is shaded with the pixel's lane in its quad, as in the single-sample kernel.
+// The other triangles of a pixel (edges: a minority of the lanes of any wavefront) are queued in LDS as
+// (pixel, triangle, weight) items and then shaded with all lanes busy, each item deriving its helper
+// pixels itself; the weighted colours meet in a per-pixel LDS accumulator (three 10-bit sums).
 template <bool FAST>
 __global__ void __launch_bounds__(256) resolve_surface_msaa_kernel(const FrameParams frame_params, ResolveInputs in, const float* __restrict__ srgb_lut,
-                                                                   const uint4* __restrict__ vis, uint32_t* __restrict__ rgba8) {
+                                                                   const uint4* __restrict__ vis, const uint32_t* __restrict__ tile_live,
+                                                                   uint32_t* __restrict__ rgba8) {
   const FrameParams* __restrict__ p = &frame_params;
   __shared__ float s_srgb[256];
+  __shared__ uint2 s_item[768];     // x: pixel (thread) | weight << 8, y: triangle id + 1
+  __shared__ uint32_t s_sum[256];   // r | g << 10 | b << 20, each a sum of up to four 8-bit values
+  __shared__ uint32_t s_items;
+  // the workgroup's 32 x 8 pixels lie in one tile of the rasteriser, which left the tile's entries unwritten if it binned nothing there
+  if (tile_live[(blockIdx.y * 8 / PBR_TILE) * p->tiles_x + blockIdx.x] == 0u) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane & 3, quad = lane >> 2;
   const int qx = blockIdx.x * 32 + quad * 2, qy = p->y0 + blockIdx.y * 8 + wave * 2;
@@ -544,32 +556,50 @@ __global__ void __launch_bounds__(256) resolve_surface_msaa_kernel(const FramePa
   const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
   const uint4 ids = live ? vis[o] : make_uint4(0u, 0u, 0u, 0u);
   const bool any = (ids.x | ids.y | ids.z | ids.w) != 0u;
+  if (threadIdx.x == 0) s_items = 0u;
+  s_sum[threadIdx.x] = 0u;
   if (__syncthreads_or(any) == 0) return;
   s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
-  __syncthreads();
-  if (__ballot(any) == 0ull) return;
-  uint32_t sum_r = 0, sum_g = 0, sum_b = 0, covered = 0;
-#pragma unroll 1
-  for (int k = 0; k < 4; ++k) {
-    const uint32_t idk = k == 0 ? ids.x : k == 1 ? ids.y : k == 2 ? ids.z : ids.w;
-    // shade on the first sample that shows a triangle; later samples of the same triangle only add to its weight
-    const bool first = idk != 0u && !(k > 0 && ids.x == idk) && !(k > 1 && ids.y == idk) && !(k > 2 && ids.z == idk);
-    const uint32_t cur = first ? idk : 0u;
-    if (__ballot(cur != 0u) == 0ull) continue;   // the same decision in every lane
-    const uint32_t c = shade_quad_lane<FAST>(p, in, s_srgb, cur, qx, qy, lane);
-    if (cur != 0u) {
-      const uint32_t count = (uint32_t)(ids.x == cur) + (uint32_t)(ids.y == cur) + (uint32_t)(ids.z == cur) + (uint32_t)(ids.w == cur);
-      sum_r += count * (c & 255u); sum_g += count * ((c >> 8) & 255u); sum_b += count * ((c >> 16) & 255u);
-      covered += count;
+  // queue the triangles of samples 1..3 that differ from every earlier sample's
+  {
+    const bool f1 = ids.y != 0u && ids.y != ids.x, f2 = ids.z != 0u && ids.z != ids.x && ids.z != ids.y,
+               f3 = ids.w != 0u && ids.w != ids.x && ids.w != ids.y && ids.w != ids.z;
+    const uint32_t n_new = (uint32_t)f1 + (uint32_t)f2 + (uint32_t)f3;
+    if (n_new) {
+      uint32_t at = atomicAdd(&s_items, n_new);
+      if (f1) s_item[at++] = make_uint2(threadIdx.x | ((1u + (uint32_t)(ids.z == ids.y) + (uint32_t)(ids.w == ids.y)) << 8), ids.y);
+      if (f2) s_item[at++] = make_uint2(threadIdx.x | ((1u + (uint32_t)(ids.w == ids.z)) << 8), ids.z);
+      if (f3) s_item[at++] = make_uint2(threadIdx.x | (1u << 8), ids.w);
     }
   }
+  __syncthreads();
+  uint32_t sum = 0u, covered = 0u;
+  if (__ballot(ids.x != 0u) != 0ull) {
+    const uint32_t c = shade_quad_lane<FAST, false>(p, in, s_srgb, ids.x, qx, qy, lane, sub);
+    if (ids.x != 0u) {
+      covered = 1u + (uint32_t)(ids.y == ids.x) + (uint32_t)(ids.z == ids.x) + (uint32_t)(ids.w == ids.x);
+      sum = covered * ((c & 255u) | (((c >> 8) & 255u) << 10) | (((c >> 16) & 255u) << 20));
+    }
+  }
+  const uint32_t n_items = s_items;
+  for (uint32_t i = threadIdx.x; i < n_items; i += 256u) {
+    const uint2 item = s_item[i];
+    const int t = (int)(item.x & 255u), weight = (int)(item.x >> 8);
+    const int tl = t & 63, ts = tl & 3;
+    const int iqx = blockIdx.x * 32 + (tl >> 2) * 2, iqy = p->y0 + blockIdx.y * 8 + (t >> 6) * 2;
+    const uint32_t c = shade_quad_lane<FAST, true>(p, in, s_srgb, item.y, iqx, iqy, lane, ts);
+    atomicAdd(&s_sum[t], (uint32_t)weight * ((c & 255u) | (((c >> 8) & 255u) << 10) | (((c >> 16) & 255u) << 20)));
+  }
+  __syncthreads();
   if (!any) return;
+  sum += s_sum[threadIdx.x];
+  covered += (uint32_t)(ids.y != 0u && ids.y != ids.x) + (uint32_t)(ids.z != 0u && ids.z != ids.x) + (uint32_t)(ids.w != 0u && ids.w != ids.x);
   if (covered < 4u) {
-    const uint32_t sky = rgba8[o], count = 4u - covered;
-    sum_r += count * (sky & 255u); sum_g += count * ((sky >> 8) & 255u); sum_b += count * ((sky >> 16) & 255u);
+    const uint32_t sky = rgba8[o];
+    sum += (4u - covered) * ((sky & 255u) | (((sky >> 8) & 255u) << 10) | (((sky >> 16) & 255u) << 20));
   }
   auto quarter = [](uint32_t v) { const uint32_t q = v >> 2, rem = v & 3u; return q + (uint32_t)(rem > 2u || (rem == 2u && (q & 1u))); };
-  rgba8[o] = quarter(sum_r) | (quarter(sum_g) << 8) | (quarter(sum_b) << 16) | 0xff000000u;
+  rgba8[o] = quarter(sum & 1023u) | (quarter((sum >> 10) & 1023u) << 8) | (quarter((sum >> 20) & 1023u) << 16) | 0xff000000u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -887,13 +917,14 @@ void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in
   }
 }
 
-void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8, int W,
-                         int rows, bool fast) {
+void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, const uint32_t* tile_live,
+                         uint8_t* rgba8, int W, int rows, bool fast) {
+  static_assert(PBR_TILE == 32, "a 32 x 8 pixel workgroup must lie inside one tile");
   dim3 grid((W + 31) / 32, (rows + 7) / 8);
   const uint4* vis4 = reinterpret_cast<const uint4*>(vis);
   uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
-  if (fast) hipLaunchKernelGGL(resolve_surface_msaa_kernel<true>, grid, dim3(256), 0, s, p, in, srgb_lut, vis4, out);
-  else hipLaunchKernelGGL(resolve_surface_msaa_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis4, out);
+  if (fast) hipLaunchKernelGGL(resolve_surface_msaa_kernel<true>, grid, dim3(256), 0, s, p, in, srgb_lut, vis4, tile_live, out);
+  else hipLaunchKernelGGL(resolve_surface_msaa_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis4, tile_live, out);
 }
 
 void launch_cube_border(hipStream_t s, DevCube src, int level, float4* dst_level) {
