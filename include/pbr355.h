@@ -95,6 +95,10 @@ int pbr_synchronize(PbrContext* ctx);
  * instance_count==1 both may be NULL and the frame's Transform is used, as in the reference. */
 int pbr_upload_mesh(PbrContext* ctx, const float* verts, int32_t n_verts, const uint16_t* indices, int32_t n_indices,
                     int32_t instance_count, const float* instance_model, const float* instance_normal);
+/* The same upload for meshes with more than 65 536 vertices (glTF componentType 5125, UNSIGNED_INT, which
+ * the reference's loader does not read: glTF.ts:222-226 builds a Uint16Array whatever the accessor says). */
+int pbr_upload_mesh_u32(PbrContext* ctx, const float* verts, int32_t n_verts, const uint32_t* indices, int32_t n_indices,
+                        int32_t instance_count, const float* instance_model, const float* instance_normal);
 
 /* ---- material textures: createTexture2DFromSource + copySourceToTexture, renderer.ts:1039-1101.
  * rgba8 is the decoded image, w*h*4 bytes, top row first.  gen_mips!=0 also builds the full chain

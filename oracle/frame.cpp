@@ -407,6 +407,8 @@ void setup_triangle(uint32_t id, V4 a, V4 b, V4 c, int W, int H, int y0, int y1,
 inline V4 load4(const float* p) { return {p[0], p[1], p[2], p[3]}; }
 inline V3 load3(const float* p) { return {p[0], p[1], p[2]}; }
 
+inline int64_t vertex_index(const OrcScene* sc, int64_t i) { return sc->indices32 ? (int64_t)sc->indices32[i] : (int64_t)sc->indices[i]; }
+
 // Sample positions inside a pixel, in 1/256 pixel: the centre, or the standard four-sample pattern of
 // D3D / Vulkan / Metal that WebGPU's `count: 4` (renderer.ts:492-501) maps to:
 // (0.375, 0.125), (0.875, 0.375), (0.125, 0.625), (0.625, 0.875).
@@ -422,9 +424,9 @@ void raster_impl(Ctx& cx, int y0, int y1, int samples, uint32_t* vis, float* dep
   for (int inst = 0; inst < sc->n_instances; ++inst)
     for (int t = 0; t < cx.n_tris; ++t) {
       int64_t base = (int64_t)inst * sc->n_verts;
-      const uint16_t* ix = sc->indices + 3 * (int64_t)t;
-      setup_triangle((uint32_t)(inst * (int64_t)cx.n_tris + t), load4(&cx.clip[4 * (base + ix[0])]),
-                     load4(&cx.clip[4 * (base + ix[1])]), load4(&cx.clip[4 * (base + ix[2])]), W, H, y0, y1, msaa, tris);
+      const int64_t i0 = vertex_index(sc, 3 * (int64_t)t), i1 = vertex_index(sc, 3 * (int64_t)t + 1), i2 = vertex_index(sc, 3 * (int64_t)t + 2);
+      setup_triangle((uint32_t)(inst * (int64_t)cx.n_tris + t), load4(&cx.clip[4 * (base + i0)]),
+                     load4(&cx.clip[4 * (base + i1)]), load4(&cx.clip[4 * (base + i2)]), W, H, y0, y1, msaa, tris);
     }
   const int rows = y1 - y0;
   for (int64_t i = 0; i < (int64_t)rows * W * samples; ++i) { vis[i] = 0; depth[i] = 1.0f; }   // renderer.ts:1943-1966
@@ -484,7 +486,7 @@ TriData fetch_tri(const Ctx& cx, uint32_t id) {
   TriData d;
   d.projective = true;
   for (int k = 0; k < 3; ++k) {
-    int vi = sc->indices[3 * (int64_t)t + k];
+    int vi = (int)vertex_index(sc, 3 * (int64_t)t + k);
     d.c[k] = load4(&cx.clip[4 * (base + vi)]);
     d.n[k] = load3(&cx.nrm[3 * (base + vi)]);
     d.p[k] = load3(&cx.world[3 * (base + vi)]);

@@ -111,6 +111,7 @@ typedef struct OrcScene {
   int32_t lut_size;
   const float* skybox;       /* [6][s][s][4] */
   int32_t sky_size;
+  const uint32_t* indices32; /* when not NULL, read instead of `indices` (meshes beyond the reference's Uint16Array) */
 } OrcScene;
 
 /* vs_main (shader.wgsl:37-47) for every instance: clip[n][4], world[n][3], nrm[n][3]. */

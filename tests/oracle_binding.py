@@ -26,6 +26,7 @@ class Scene(C.Structure):
         ("inst_model", C.c_void_p), ("inst_normal", C.c_void_p), ("tex", C.c_void_p * 5), ("tex_w", C.c_int32 * 5), ("tex_h", C.c_int32 * 5),
         ("tex_levels", C.c_int32 * 5), ("irradiance", C.c_void_p), ("irr_size", C.c_int32), ("prefilter", C.c_void_p), ("pre_size", C.c_int32),
         ("pre_levels", C.c_int32), ("lut_f16", C.c_void_p), ("lut_size", C.c_int32), ("skybox", C.c_void_p), ("sky_size", C.c_int32),
+        ("indices32", C.c_void_p),
     ]
 
 

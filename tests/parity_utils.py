@@ -34,7 +34,8 @@ class OracleScene:
         lib = ob.load()
         self.lib = lib
         self.verts = np.ascontiguousarray(geometry.vertices, dtype=np.float32)
-        self.indices = np.ascontiguousarray(geometry.indices, dtype=np.uint16)
+        wide = np.asarray(geometry.indices).dtype == np.uint32
+        self.indices = np.ascontiguousarray(geometry.indices, dtype=np.uint32 if wide else np.uint16)
         srgb = [True, False, False, True, False]
         self.chains = []
         self.levels = []
@@ -68,7 +69,11 @@ class OracleScene:
         m = self.maps()
         sc = ob.Scene()
         sc.verts = ob.ptr(self.verts); sc.n_verts = self.verts.size // 8
-        sc.indices = ob.ptr(self.indices); sc.n_indices = self.indices.size
+        if self.indices.dtype == np.uint32:
+            sc.indices32 = ob.ptr(self.indices)
+        else:
+            sc.indices = ob.ptr(self.indices)
+        sc.n_indices = self.indices.size
         if self.inst_model is not None:
             sc.n_instances = len(self.inst_model)
             sc.inst_model = ob.ptr(self.inst_model); sc.inst_normal = ob.ptr(self.inst_normal)

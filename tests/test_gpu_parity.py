@@ -431,3 +431,21 @@ def test_general_gltf_scene_matches_oracle(tmp_path):
     assert (vis > 0).mean() > 0.05 and set(np.unique(vis)) == {0, 1, 2}
     assert (vis == ovis).all()
     assert_frame_close(rgba, orgba, vis, ovis, "interleaved quad")
+
+
+def test_wide_index_mesh_matches_oracle(tmp_path):
+    """A mesh of 73 988 vertices in two primitives: 32-bit indices from the loader through the C ABI to the
+    kernels (pbr_upload_mesh_u32), against the oracle reading the same 32-bit indices."""
+    import gltf_samples
+    path, verts, indices = gltf_samples.write_large_two_primitive_mesh(str(tmp_path))
+    scene = pu.SmallScene.build(width=384, height=216, model_path=path, reference_limits=False)
+    assert scene.renderer.geometries[0].indices.dtype == np.uint32
+    for msaa in (False, True):
+        scene.renderer.msaa_options["enable"] = msaa
+        rgba, vis = scene.render_gpu()
+        orgba, ovis = scene.render_oracle()
+        assert (vis == ovis).all()
+        assert_frame_close(rgba, orgba, vis, ovis, f"height field msaa={msaa}")
+        ids = np.unique(vis)
+        assert ids.max() > 65536 * 2 and (vis > 0).mean() > 0.2      # triangles far beyond 16-bit vertex numbers are visible
+    scene.renderer.close()

@@ -227,3 +227,23 @@ def test_gltf_loader_without_reference_limits(tmp_path, pkg):
     # the reference's loader has no material guards (glTF.ts:228-252): the default mirrors its failure
     with pytest.raises((KeyError, RuntimeError, ValueError)):
         pkg.glTFLoader().load(path)
+
+
+def test_gltf_loader_joins_primitives_with_wide_indices(tmp_path, pkg):
+    """Beyond 65 536 vertices the general loader hands over 32-bit indices; all triangle primitives of the mesh
+    become one geometry, later primitives' indices shifted past the earlier vertices, other modes skipped."""
+    import gltf_samples
+    path, verts, indices = gltf_samples.write_large_two_primitive_mesh(str(tmp_path))
+    loader = pkg.glTFLoader(reference_limits=False)
+    loader.load(path)
+    g = loader.get_geometries()[0]
+    assert g.indices.dtype == np.uint32 and np.array_equal(g.indices, indices)
+    assert np.array_equal(g.vertices.reshape(-1, 8), verts) and verts.shape[0] == 272 * 272 + 4 > 65536
+    assert int(g.indices[-6:].min()) == 272 * 272
+    # a small mesh of several primitives stays at 16 bits
+    os.makedirs(tmp_path / "small")
+    small_path, sverts, sindices = gltf_samples.write_large_two_primitive_mesh(str(tmp_path / "small"), n=16)
+    small = pkg.glTFLoader(reference_limits=False)
+    small.load(small_path)
+    gs = small.get_geometries()[0]
+    assert gs.indices.dtype == np.uint16 and np.array_equal(gs.indices, sindices) and np.array_equal(gs.vertices.reshape(-1, 8), sverts)

@@ -59,8 +59,14 @@ def general_gltf(tmp_path_factory):
 
 
 @pytest.fixture(scope="module")
-def js_dump(small_hdr, older_hdrs, general_gltf):
-    proc = subprocess.run(["node", os.path.join(HOST, "test", "dump_host.js"), MODEL, small_hdr, ALBEDO, older_hdrs[0], older_hdrs[1], general_gltf], stdout=subprocess.PIPE,
+def large_gltf(tmp_path_factory):
+    import gltf_samples
+    return gltf_samples.write_large_two_primitive_mesh(str(tmp_path_factory.mktemp("large")))[0]
+
+
+@pytest.fixture(scope="module")
+def js_dump(small_hdr, older_hdrs, general_gltf, large_gltf):
+    proc = subprocess.run(["node", os.path.join(HOST, "test", "dump_host.js"), MODEL, small_hdr, ALBEDO, older_hdrs[0], older_hdrs[1], general_gltf, large_gltf], stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, text=True, timeout=120)
     assert proc.returncode == 0, proc.stderr
     return json.loads(proc.stdout)
@@ -93,6 +99,17 @@ def test_general_gltf_loader_matches(js_dump, general_gltf, pkg):
     assert j["model"] == _hex(np.asarray(g.model, dtype=np.float32))
     assert all(j["textures"][k] is None for k in ("baseColorURI", "metallicRoughnessURI", "normalURI", "emissiveURI", "occlusionURI"))
     assert j["textures"]["emissive"] == [0, 0, 0]
+
+
+@needs_node
+def test_large_multi_primitive_gltf_matches(js_dump, large_gltf, pkg):
+    loader = pkg.glTFLoader(reference_limits=False)
+    loader.load(large_gltf)
+    g = loader.get_geometries()[0]
+    j = js_dump["largeGeometry"]
+    assert j["indexBytes"] == 4 and g.indices.dtype == np.uint32
+    assert j["vertices"] == _sha(g.vertices.astype(np.float32)) and j["indices"] == _sha(g.indices)
+    assert j["model"] == _hex(np.asarray(g.model, dtype=np.float32))
 
 
 @needs_node

@@ -40,6 +40,7 @@ EXPORTS = {
     "pbr_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pbr_synchronize": (C.c_int, [C.c_void_p]),
     "pbr_upload_mesh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pbr_upload_mesh_u32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pbr_upload_texture": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pbr_upload_hdr": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     "pbr_ibl_equirect_to_cube": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -469,15 +469,23 @@ int pbr_synchronize(PbrContext* c) {
   return check_sticky(c);
 }
 
-int pbr_upload_mesh(PbrContext* c, const float* verts, int32_t n_verts, const uint16_t* indices, int32_t n_indices,
-                    int32_t instance_count, const float* instance_model, const float* instance_normal) {
+// Both index widths end up as 32-bit indices on the device: the index stream is a few hundred kilobytes a
+// frame against hundreds of megabytes of pixel traffic, and one width keeps one set of kernels.
+static int upload_mesh_common(PbrContext* c, const float* verts, int32_t n_verts, const uint16_t* idx16, const uint32_t* idx32, int32_t n_indices,
+                              int32_t instance_count, const float* instance_model, const float* instance_normal) {
   if (!c) return PBR_E_ARG;
-  if (!verts || !indices || n_verts <= 0 || n_indices <= 0) return fail(c, PBR_E_ARG, "empty mesh");
+  if (!verts || (!idx16 && !idx32) || n_verts <= 0 || n_indices <= 0) return fail(c, PBR_E_ARG, "empty mesh");
   if (n_indices % 3) return fail(c, PBR_E_ARG, "index count %d is not a multiple of 3 (triangle-list)", n_indices);
   if (instance_count < 1) return fail(c, PBR_E_ARG, "instance count must be at least 1");
   if (instance_count > 1 && (!instance_model || !instance_normal)) return fail(c, PBR_E_ARG, "instanced upload needs model and normal matrices");
   if ((uint64_t)instance_count * (uint64_t)(n_indices / 3) >= 0xffffffffull) return fail(c, PBR_E_ARG, "too many triangles for 32-bit visibility ids");
-  for (int32_t i = 0; i < n_indices; ++i) if (indices[i] >= n_verts) return fail(c, PBR_E_ARG, "index %d refers to vertex %u of %d", i, indices[i], n_verts);
+  if ((uint64_t)instance_count * (uint64_t)n_verts > 0x7fffffffull) return fail(c, PBR_E_ARG, "too many vertices");
+  std::vector<uint32_t> wide((size_t)n_indices);
+  for (int32_t i = 0; i < n_indices; ++i) {
+    const uint32_t v = idx16 ? (uint32_t)idx16[i] : idx32[i];
+    if (v >= (uint32_t)n_verts) return fail(c, PBR_E_ARG, "index %d refers to vertex %u of %d", i, v, n_verts);
+    wide[i] = v;
+  }
   DeviceGuard guard(c->device);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   free_dev(c->d_vsoa); free_dev(c->d_indices); free_dev(c->d_inst_model); free_dev(c->d_inst_normal);
@@ -490,8 +498,8 @@ int pbr_upload_mesh(PbrContext* c, const float* verts, int32_t n_verts, const ui
   }
   HIP_TRY(c, hipMalloc(&c->d_vsoa, soa.size() * sizeof(float)));
   HIP_TRY(c, hipMemcpy(c->d_vsoa, soa.data(), soa.size() * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMalloc(&c->d_indices, (size_t)n_indices * sizeof(uint16_t)));
-  HIP_TRY(c, hipMemcpy(c->d_indices, indices, (size_t)n_indices * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMalloc(&c->d_indices, wide.size() * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemcpy(c->d_indices, wide.data(), wide.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
   c->has_instance_mats = instance_model && instance_normal;
   if (c->has_instance_mats) {
     const size_t bytes = (size_t)instance_count * 16 * sizeof(float);
@@ -502,6 +510,16 @@ int pbr_upload_mesh(PbrContext* c, const float* verts, int32_t n_verts, const ui
   }
   c->n_verts = n_verts; c->n_indices = n_indices; c->n_instances = instance_count;
   return PBR_OK;
+}
+
+int pbr_upload_mesh(PbrContext* c, const float* verts, int32_t n_verts, const uint16_t* indices, int32_t n_indices,
+                    int32_t instance_count, const float* instance_model, const float* instance_normal) {
+  return upload_mesh_common(c, verts, n_verts, indices, nullptr, n_indices, instance_count, instance_model, instance_normal);
+}
+
+int pbr_upload_mesh_u32(PbrContext* c, const float* verts, int32_t n_verts, const uint32_t* indices, int32_t n_indices,
+                        int32_t instance_count, const float* instance_model, const float* instance_normal) {
+  return upload_mesh_common(c, verts, n_verts, nullptr, indices, n_indices, instance_count, instance_model, instance_normal);
 }
 
 int pbr_upload_texture(PbrContext* c, int slot, const uint8_t* rgba8, int32_t w, int32_t h, int32_t is_srgb, int32_t gen_mips) {

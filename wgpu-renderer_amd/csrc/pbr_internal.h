@@ -104,7 +104,7 @@ struct PbrContext {
 
   // mesh (SoA vertex streams)
   float* d_vsoa = nullptr;          // 8 streams of n_verts floats: px py pz u v nx ny nz
-  uint16_t* d_indices = nullptr;
+  uint32_t* d_indices = nullptr;
   float* d_inst_model = nullptr;    // [n_instances][16]
   float* d_inst_normal = nullptr;
   int32_t n_verts = 0, n_indices = 0, n_instances = 0;
@@ -164,7 +164,7 @@ void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa,
 // where the setup kernel takes a triangle's vertices from: transformed vertices in memory (vout), or the
 // vertex streams, transformed on the fly (vsoa set, vout unused)
 struct VertexSource { const VertexOut* vout; const float* vsoa; const float* inst_model; const float* inst_normal; };
-void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint16_t* indices, SetupTri* setup, TriRecord* records,
+void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint32_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           int n_tris, int n_instances, const SkyShare& share);
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
@@ -173,7 +173,7 @@ void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, u
 struct ResolveInputs {
   const TriRecord* records;
   const VertexOut* vout;
-  const uint16_t* indices;
+  const uint32_t* indices;
   DevTex8 tex[5];
   DevCube irr, pre, sky;
   DevCube irr_b, pre_b, sky_b;   // the same maps with a one-texel border per face (level l: [6][n+2][n+2], n = size >> l)

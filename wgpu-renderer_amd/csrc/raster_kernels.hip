@@ -195,10 +195,10 @@ PBR_DEV void write_record(TriRecord* __restrict__ dst, const VertexOut& a, const
   if (!projective) { d[9] = ca; d[10] = cb; d[11] = cc; }   // only the homogeneous fallback of the resolve reads these
 }
 
-PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint16_t* indices, const BinTargets& bt, int inst, int t, int n_tris,
+PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint32_t* indices, const BinTargets& bt, int inst, int t, int n_tris,
                        Deferred* defer) {
   const size_t base = (size_t)inst * p->n_verts;
-  const int ia = indices[3 * t], ib = indices[3 * t + 1], ic = indices[3 * t + 2];
+  const int ia = (int)indices[3 * (size_t)t], ib = (int)indices[3 * (size_t)t + 1], ic = (int)indices[3 * (size_t)t + 2];
   VertexOut va, vb, vc;
   if (bt.vsoa) {
     VertexMatrices m;
@@ -251,7 +251,7 @@ PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint16
 }
 
 __global__ void __launch_bounds__(256) setup_kernel(const FrameParams frame_params, const VertexOut* __restrict__ vout,
-                                                    const uint16_t* __restrict__ indices, BinTargets bt, int n_tris, int blocks_per_instance,
+                                                    const uint32_t* __restrict__ indices, BinTargets bt, int n_tris, int blocks_per_instance,
                                                     SkyShare share) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   if ((int)blockIdx.x >= share.own_blocks) { sky_tile(p, share.sky, share.rgba8, share.first + (int)blockIdx.x - share.own_blocks); return; }
@@ -661,7 +661,7 @@ void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa,
                      share);
 }
 
-void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint16_t* indices, SetupTri* setup, TriRecord* records,
+void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint32_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           int n_tris, int n_instances, const SkyShare& share_in) {
   // tile_count is zero on entry (the raster kernel of the previous frame clears it) and so are the

@@ -460,7 +460,7 @@ PBR_DEV uint32_t shade_quad_lane(const FrameParams* p, const ResolveInputs& in, 
     uint32_t inst = 0, tri = id - 1u;
     if (p->n_instances > 1) { inst = tri / (uint32_t)p->n_tris; tri -= inst * (uint32_t)p->n_tris; }
     const VertexOut* vb = in.vout + (size_t)inst * p->n_verts;
-    const VertexOut v0 = vb[in.indices[3 * tri]], v1 = vb[in.indices[3 * tri + 1]], v2 = vb[in.indices[3 * tri + 2]];
+    const VertexOut v0 = vb[in.indices[3 * (size_t)tri]], v1 = vb[in.indices[3 * (size_t)tri + 1]], v2 = vb[in.indices[3 * (size_t)tri + 2]];
     t.c0 = v0.clip; t.c1 = v1.clip; t.c2 = v2.clip;
     t.p0 = v3(v0.world_u.x, v0.world_u.y, v0.world_u.z); t.p1 = v3(v1.world_u.x, v1.world_u.y, v1.world_u.z); t.p2 = v3(v2.world_u.x, v2.world_u.y, v2.world_u.z);
     t.n0 = v3(v0.nrm_v.x, v0.nrm_v.y, v0.nrm_v.z); t.n1 = v3(v1.nrm_v.x, v1.nrm_v.y, v1.nrm_v.z); t.n2 = v3(v2.nrm_v.x, v2.nrm_v.y, v2.nrm_v.z);

@@ -4,9 +4,11 @@ limits: one buffer view per attribute read from its start, a fixed 8-float verte
 the last primitive of a node wins, and node matrix = I * scale * translate * rotation.
 
 `glTFLoader(reference_limits=False)` reads accessors the way the glTF 2.0 specification defines
-them instead (accessor.byteOffset, bufferView.byteStride, 8/16/32-bit indices as long as the
-vertex count fits 16-bit indices) and tolerates a material without some of the five textures
-(the missing URI is None and the renderer substitutes a neutral 1x1 texture)."""
+them instead (accessor.byteOffset, bufferView.byteStride, 8/16/32-bit indices), joins all triangle
+primitives of a node's mesh into one geometry drawn with the first primitive's material (the
+renderer binds one material per draw), and tolerates a material without some of the five textures
+(the missing URI is None and the renderer substitutes a neutral 1x1 texture).  The joined indices
+are uint16 while the vertex count allows it and uint32 beyond."""
 import json
 import os
 from dataclasses import dataclass, field
@@ -123,13 +125,13 @@ class glTFLoader:  # noqa: N801 - the reference's class name
         attrs = primitive["attributes"]
         uv = self._accessor(attrs["TEXCOORD_0"]).astype(np.float32) if "TEXCOORD_0" in attrs else np.zeros((count, 2), np.float32)
         nrm = self._accessor(attrs["NORMAL"]).astype(np.float32) if "NORMAL" in attrs else np.tile(np.float32([0, 0, 1]), (count, 1))
-        if count > 65536:
-            raise RuntimeError("More than 65536 vertices in one primitive: the draw path indexes with 16 bits.")
         vertices = np.concatenate([pos[:, :3], uv[:, :2], nrm[:, :3]], axis=1).astype(np.float32).reshape(-1)
         if "indices" in primitive:
-            indices = self._accessor(primitive["indices"]).reshape(-1).astype(np.uint16)
+            indices = self._accessor(primitive["indices"]).reshape(-1).astype(np.uint32)
         else:
-            indices = np.arange(count, dtype=np.uint16)
+            indices = np.arange(count, dtype=np.uint32)
+        if indices.size and int(indices.max()) >= count:
+            raise RuntimeError("Index refers to a vertex the primitive does not have.")
         material = g.get("materials", [{}])[primitive.get("material", 0)] if g.get("materials") else {}
         pbr = material.get("pbrMetallicRoughness", {})
 
@@ -162,14 +164,19 @@ class glTFLoader:  # noqa: N801 - the reference's class name
                     q = np.asarray(node["rotation"], dtype=np.float32)
                     model = mathx.mul(model, mathx.from_quat(q))                      # glTF.ts:126-129
             mesh = g["meshes"][node["mesh"]]
+            if not self.reference_limits:
+                parts = [self._general_primitive(pr) for pr in mesh["primitives"] if pr.get("mode", 4) == 4]
+                if parts:
+                    first = np.cumsum([0] + [v.size // 8 for v, _, _ in parts])
+                    indices = np.concatenate([ix + np.uint32(first[k]) for k, (_, ix, _) in enumerate(parts)])
+                    if first[-1] <= 65536:
+                        indices = indices.astype(np.uint16)
+                    self.geometries[index] = Geometry(model=model, vertices=np.concatenate([v for v, _, _ in parts]), array_stride=32,
+                                                      position=Layout("float32x3", 0), tex_coord=Layout("float32x2", 12), normal=Layout("float32x3", 20),
+                                                      indices=indices, textures=parts[0][2])
+                continue
             for primitive in mesh["primitives"]:
                 if "mode" in primitive and primitive["mode"] != 4:                    # glTF.ts:134-136
-                    continue
-                if not self.reference_limits:
-                    vertices, indices, textures = self._general_primitive(primitive)
-                    self.geometries[index] = Geometry(model=model, vertices=vertices, array_stride=32, position=Layout("float32x3", 0),
-                                                      tex_coord=Layout("float32x2", 12), normal=Layout("float32x3", 20), indices=indices,
-                                                      textures=textures)
                     continue
                 pos_acc = g["accessors"][primitive["attributes"]["POSITION"]]
                 uv_acc = g["accessors"][primitive["attributes"]["TEXCOORD_0"]]

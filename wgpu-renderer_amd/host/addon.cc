@@ -61,6 +61,14 @@ struct Args {
     return true;
   }
   // a TypedArray of the given element type (or, for bytes, also an ArrayBuffer / Buffer)
+  // element type of a typed-array argument (napi_int8_array when the value is not a typed array)
+  napi_typedarray_type element_type(size_t i) const {
+    bool is_ta = false;
+    napi_is_typedarray(env, argv[i], &is_ta);
+    napi_typedarray_type type = napi_int8_array; napi_value ab; size_t off, count; void* data;
+    if (is_ta) napi_get_typedarray_info(env, argv[i], &type, &count, &data, &ab, &off);
+    return type;
+  }
   bool typed(size_t i, napi_typedarray_type want, void** data, size_t* count) const {
     bool is_ta = false;
     napi_is_typedarray(env, argv[i], &is_ta);
@@ -141,7 +149,7 @@ napi_value Synchronize(napi_env env, napi_callback_info info) {
   return undefined_value(env);
 }
 
-// uploadMesh(ctx, Float32Array vertices, Uint16Array indices[, instanceCount, Float32Array models, Float32Array normals])
+// uploadMesh(ctx, Float32Array vertices, Uint16Array | Uint32Array indices[, instanceCount, Float32Array models, Float32Array normals])
 //                                                               [createVertexBuffer/createIndexBuffer, renderer.ts:504-540]
 napi_value UploadMesh(napi_env env, napi_callback_info info) {
   Args a(env, info, 3, "uploadMesh(ctx, vertices, indices[, instanceCount, models, normals])");
@@ -149,16 +157,19 @@ napi_value UploadMesh(napi_env env, napi_callback_info info) {
   if (!a.ok || !a.ctx(0, &ctx)) return nullptr;
   void *v, *idx, *models = nullptr, *normals = nullptr;
   size_t nv, ni, nm = 0, nn = 0;
-  if (!a.typed(1, napi_float32_array, &v, &nv) || !a.typed(2, napi_uint16_array, &idx, &ni)) return nullptr;
+  const bool wide = a.element_type(2) == napi_uint32_array;
+  if (!a.typed(1, napi_float32_array, &v, &nv) || !a.typed(2, wide ? napi_uint32_array : napi_uint16_array, &idx, &ni)) return nullptr;
   int32_t instances = 1;
   if (!a.is_nullish(3) && !a.i32(3, &instances)) return nullptr;
   if (!a.is_nullish(4) && !a.typed(4, napi_float32_array, &models, &nm)) return nullptr;
   if (!a.is_nullish(5) && !a.typed(5, napi_float32_array, &normals, &nn)) return nullptr;
   if (nv % 8) { napi_throw_range_error(env, nullptr, "vertices must hold 8 floats per vertex"); return nullptr; }
   if (models && (instances < 1 || nm != (size_t)instances * 16 || nn != nm)) { napi_throw_range_error(env, nullptr, "instance matrices must hold 16 floats per instance"); return nullptr; }
-  if (!check(env, ctx, pbr_upload_mesh(ctx, static_cast<float*>(v), (int32_t)(nv / 8), static_cast<uint16_t*>(idx), (int32_t)ni, instances,
-                                       static_cast<float*>(models), static_cast<float*>(normals))))
-    return nullptr;
+  const int rc = wide ? pbr_upload_mesh_u32(ctx, static_cast<float*>(v), (int32_t)(nv / 8), static_cast<uint32_t*>(idx), (int32_t)ni, instances,
+                                            static_cast<float*>(models), static_cast<float*>(normals))
+                      : pbr_upload_mesh(ctx, static_cast<float*>(v), (int32_t)(nv / 8), static_cast<uint16_t*>(idx), (int32_t)ni, instances,
+                                        static_cast<float*>(models), static_cast<float*>(normals));
+  if (!check(env, ctx, rc)) return nullptr;
   return undefined_value(env);
 }
 

@@ -4,9 +4,11 @@
 // whole bufferViews (accessor offsets and strides are ignored), expects float32 POSITION /
 // TEXCOORD_0 / NORMAL and uint16 indices, and takes every material texture without guards.
 // `new glTFLoader({ referenceLimits: false })` reads accessors as the glTF 2.0 specification defines
-// them instead (accessor.byteOffset, bufferView.byteStride, 8/16/32-bit indices while the vertex
-// count fits 16-bit indices) and tolerates missing material textures (URI null; the renderer
-// substitutes a neutral 1x1 texture).
+// them instead (accessor.byteOffset, bufferView.byteStride, 8/16/32-bit indices), joins all triangle
+// primitives of a node's mesh into one geometry drawn with the first primitive's material (the
+// renderer binds one material per draw) and tolerates missing material textures (URI null; the
+// renderer substitutes a neutral 1x1 texture).  The joined indices are a Uint16Array while the vertex
+// count allows it and a Uint32Array beyond.
 const fs = require('fs');
 const { mat4 } = require('./mat.js');
 const { calculateByteLength } = require('./utils.js');
@@ -90,7 +92,6 @@ class glTFLoader {   // eslint-disable-line camelcase -- the reference's class n
     const g = this.gltf;
     const pos = this.accessor(primitive.attributes.POSITION);
     const count = pos.count;
-    if (count > 65536) throw new Error('More than 65536 vertices in one primitive: the draw path indexes with 16 bits.');
     const uv = primitive.attributes.TEXCOORD_0 !== undefined ? this.accessor(primitive.attributes.TEXCOORD_0) : null;
     const nrm = primitive.attributes.NORMAL !== undefined ? this.accessor(primitive.attributes.NORMAL) : null;
     const vertices = new Float32Array(count * 8);
@@ -100,8 +101,9 @@ class glTFLoader {   // eslint-disable-line camelcase -- the reference's class n
       for (let k = 0; k < 3; ++k) vertices[8 * i + 5 + k] = nrm ? nrm.data[nrm.comps * i + k] : (k === 2 ? 1 : 0);
     }
     let indices;
-    if (primitive.indices !== undefined) indices = Uint16Array.from(this.accessor(primitive.indices).data);
-    else indices = Uint16Array.from({ length: count }, (_, i) => i);
+    if (primitive.indices !== undefined) indices = Uint32Array.from(this.accessor(primitive.indices).data);
+    else indices = Uint32Array.from({ length: count }, (_, i) => i);
+    for (const v of indices) if (v >= count) throw new Error('Index refers to a vertex the primitive does not have.');
     const material = (g.materials && g.materials[primitive.material || 0]) || {};
     const pbr = material.pbrMetallicRoughness || {};
     const uri = (slot) => (slot && slot.index !== undefined ? this.pathname + g.images[g.textures[slot.index].source].uri : null);
@@ -125,14 +127,24 @@ class glTFLoader {   // eslint-disable-line camelcase -- the reference's class n
         if (node.translation) model = mat4.translate(model, node.translation);   // glTF.ts:122-124
         if (node.rotation) model = mat4.mul(model, mat4.fromQuat(new Float32Array(node.rotation)));   // glTF.ts:126-129
       }
+      if (!this.referenceLimits) {
+        const parts = g.meshes[node.mesh].primitives.filter((pr) => pr.mode === undefined || pr.mode === 4).map((pr) => this.generalPrimitive(pr));
+        if (parts.length === 0) return;
+        const nVerts = parts.reduce((n, part) => n + part.vertices.length / 8, 0), nIndices = parts.reduce((n, part) => n + part.indices.length, 0);
+        const vertices = new Float32Array(nVerts * 8);
+        const indices = nVerts <= 65536 ? new Uint16Array(nIndices) : new Uint32Array(nIndices);
+        let firstVertex = 0, firstIndex = 0;
+        for (const part of parts) {
+          vertices.set(part.vertices, firstVertex * 8);
+          for (let i = 0; i < part.indices.length; ++i) indices[firstIndex + i] = part.indices[i] + firstVertex;
+          firstVertex += part.vertices.length / 8; firstIndex += part.indices.length;
+        }
+        this.geometries[index] = { model, vertices, arrayStride: 32, position: { format: 'float32x3', offset: 0 },
+          texCoord: { format: 'float32x2', offset: 12 }, normal: { format: 'float32x3', offset: 20 }, indices, textures: parts[0].textures };
+        return;
+      }
       for (const primitive of g.meshes[node.mesh].primitives) {
         if (primitive.mode !== undefined && primitive.mode !== 4) continue;     // glTF.ts:134-136: triangle lists only
-        if (!this.referenceLimits) {
-          const general = this.generalPrimitive(primitive);
-          this.geometries[index] = { model, vertices: general.vertices, arrayStride: 32, position: { format: 'float32x3', offset: 0 },
-            texCoord: { format: 'float32x2', offset: 12 }, normal: { format: 'float32x3', offset: 20 }, indices: general.indices, textures: general.textures };
-          continue;
-        }
         const posAcc = g.accessors[primitive.attributes.POSITION];
         const uvAcc = g.accessors[primitive.attributes.TEXCOORD_0];
         const nrmAcc = g.accessors[primitive.attributes.NORMAL];

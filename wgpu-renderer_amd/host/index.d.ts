@@ -15,7 +15,7 @@ export type Geometry = {
   position: Layout;
   normal: Layout;
   texCoord: Layout;
-  indices: Uint16Array;
+  indices: Uint16Array | Uint32Array;   // 32-bit only from the general loader, for meshes beyond 65 536 vertices
   textures: {
     baseColorURI: string;
     metallicRoughnessURI: string;

@@ -20,6 +20,7 @@ if (require.main === module) {
   (async () => {
     await renderer.init();
     for (let i = 0; i < (int('orbit') || 0); ++i) renderer.camera.updateCameraRotation(-10, 0);
+    if (args.msaa === '1') renderer.msaaOptions.enable = true;   // the MSAA checkbox, renderer.ts:1793-1800
     const frame = renderer.drawFrame({ wantVis: args.vis !== undefined });
     if (args.out) fs.writeFileSync(args.out, frame.rgba);
     if (args.vis) fs.writeFileSync(args.vis, Buffer.from(frame.vis.buffer));

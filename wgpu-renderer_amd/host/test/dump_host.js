@@ -9,7 +9,7 @@ const sha = (typed) => crypto.createHash('sha256').update(Buffer.from(typed.buff
 const hex = (typed) => Buffer.from(typed.buffer, typed.byteOffset, typed.byteLength).toString('hex');
 
 (async () => {
-  const [modelPath, hdrPath, jpegPath, flatPath, oldRlePath, generalModelPath] = process.argv.slice(2);
+  const [modelPath, hdrPath, jpegPath, flatPath, oldRlePath, generalModelPath, largeModelPath] = process.argv.slice(2);
   const out = {};
   const loader = new host.glTFLoader();
   await loader.load(modelPath);
@@ -20,6 +20,10 @@ const hex = (typed) => Buffer.from(typed.buffer, typed.byteOffset, typed.byteLen
   await general.load(generalModelPath);
   const gg = general.getGeometries()[0];
   out.generalGeometry = { vertices: sha(gg.vertices), indices: sha(gg.indices), model: hex(gg.model), textures: gg.textures };
+  const large = new host.glTFLoader({ referenceLimits: false });
+  await large.load(largeModelPath);
+  const lg = large.getGeometries()[0];
+  out.largeGeometry = { vertices: sha(lg.vertices), indices: sha(lg.indices), indexBytes: lg.indices.BYTES_PER_ELEMENT, model: hex(lg.model) };
   const hdrLoader = new host.HDRLoader();
   await hdrLoader.load(hdrPath);
   out.hdr = { width: hdrLoader.hdr.width, height: hdrLoader.hdr.height, data: sha(hdrLoader.hdr.data) };

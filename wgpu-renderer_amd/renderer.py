@@ -99,14 +99,16 @@ class Renderer:
     def create_vertex_buffer(self):
         g = self.geometries[0]                                     # renderer.ts:506, :525: only geometry 0 is drawn
         verts = np.ascontiguousarray(g.vertices, dtype=np.float32)
-        idx = np.ascontiguousarray(g.indices, dtype=np.uint16)
+        # the reference's Uint16Array (glTF.ts:222-226); the general loader hands over uint32 for larger meshes
+        wide = np.asarray(g.indices).dtype == np.uint32
+        idx = np.ascontiguousarray(g.indices, dtype=np.uint32 if wide else np.uint16)
+        upload = self._lib.pbr_upload_mesh_u32 if wide else self._lib.pbr_upload_mesh
         if self.instance_models is None:
-            self._check(self._lib.pbr_upload_mesh(self._ctx, _fptr(verts), verts.size // 8, _fptr(idx), idx.size, 1, None, None))
+            self._check(upload(self._ctx, _fptr(verts), verts.size // 8, _fptr(idx), idx.size, 1, None, None))
         else:
             models = np.ascontiguousarray(self.instance_models, dtype=np.float32).reshape(-1, 16)
             normals = np.stack([mathx.transpose(mathx.inverse(m)) for m in models]).astype(np.float32)
-            self._check(self._lib.pbr_upload_mesh(self._ctx, _fptr(verts), verts.size // 8, _fptr(idx), idx.size, len(models),
-                                                  _fptr(models), _fptr(normals)))
+            self._check(upload(self._ctx, _fptr(verts), verts.size // 8, _fptr(idx), idx.size, len(models), _fptr(models), _fptr(normals)))
 
     def create_texture(self):
         """renderer.ts:604-860: material textures (with their mip chains), irradiance and prefilter
