@@ -138,8 +138,6 @@ struct PbrContext {
   uint32_t* h_counters = nullptr; // pinned mirror
   uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0, vis_cap = 0;   // vis / depth hold vis_cap entries (one per sample)
   int32_t last_w = 0, last_rows = 0, last_samples = 1;
-  FrameParams* d_params = nullptr;
-  FrameParams* h_params = nullptr;   // pinned staging
 
   // timing
   hipEvent_t ev[6] = {};
