@@ -135,9 +135,9 @@ def test_camera_views_match_oracle(small, moves):
 def test_orbit_sweep_matches_oracle(small):
     """Every tenth frame of the 360-frame orbit of the benchmark (updateCameraRotation(-10, 0) per frame, camera.ts:163-183):
     the visibility buffer is the oracle's on every frame, the colours stay within the frame tolerance.  A few
-    pixels per million sit in quads shared with another triangle whose helper invocations are extrapolated
-    far outside their own, ill-conditioned triangle; there the last-bit differences between the two
-    implementations (reciprocal approximations, FMA contraction) are amplified beyond 2/255."""
+    pixels per million differ by more: all the pixels of one triangle in a quad it shares with others, as when
+    derivatives that differ in the last bits (reciprocal approximations, FMA contraction) put the mip level on
+    the other side of a rounding boundary."""
     cam = small.pkg.Camera()
     small.renderer.camera = cam
     beyond, mismatched = 0, 0
