@@ -342,3 +342,109 @@ def test_raster_clips_against_the_near_plane():
     lib.orc_raster(C.byref(sc), C.byref(u), W, H, 0, H, ob.ptr(vis), ob.ptr(depth))
     assert (vis > 0).sum() > 50
     assert depth[vis > 0].min() >= 0.0 and depth[vis > 0].max() < 1.0
+
+
+# ---- fs_main against an independent float64 evaluation ----
+def test_fragment_shading_matches_a_float64_evaluation():
+    """shader.wgsl:93-160 evaluated in float64 numpy, written from the WGSL alone, for a scene where every lookup is a
+    constant (1x1 material textures, one-texel cube maps, a flat BRDF table): the oracle's f32 frame must agree to
+    the last 8-bit step on (almost) every pixel.  Pins the TBN construction, the four-light Cook-Torrance loop, the
+    split-sum ambient term, the sRGB decode of the colour textures and the gamma curve."""
+    lib = ob.load()
+    W, H = 64, 36
+    fov, near, far = math.radians(45.0), 1.0, 100.0
+    eye = np.array([0.0, 0.0, 5.0])
+    quad = np.float32([[-1.5, -1.5, 0], [1.5, -1.5, 0], [1.5, 1.5, 0], [-1.5, 1.5, 0]])
+    v = np.zeros((4, 8), np.float32)
+    v[:, :3] = quad
+    v[:, 3] = (quad[:, 0] + 1.5) / 3.0; v[:, 4] = (1.5 - quad[:, 1]) / 3.0
+    v[:, 5:8] = [0, 0, 1]
+    idx = np.array([0, 1, 2, 0, 2, 3], np.uint16)
+    texel = {"albedo": (200, 120, 60, 255), "mr": (0, 140, 180, 255), "normal": (150, 100, 240, 255), "emissive": (30, 60, 90, 255), "occlusion": (210, 0, 0, 255)}
+    chains = [np.array(texel[k], np.uint8) for k in ("albedo", "mr", "normal", "emissive", "occlusion")]
+    irr_c, pre_c, lut_c = np.float32([0.25, 0.5, 0.75, 1.0]), np.float32([0.9, 0.6, 0.3, 1.0]), np.float32([0.7, 0.1, 0.0, 1.0])
+    irr = np.tile(irr_c, (6, 1)).astype(np.float32); pre = np.tile(pre_c, (6, 1)).astype(np.float32); sky = np.tile(np.float32([0, 0, 0, 1]), (6, 1))
+    lut = np.tile(lut_c.astype(np.float16).view(np.uint16), (4, 1))                     # 2 x 2 table
+    sc = _tiny_scene(v, idx)
+    for i, ch in enumerate(chains):
+        sc.tex[i] = ob.ptr(ch).value; sc.tex_w[i] = 1; sc.tex_h[i] = 1; sc.tex_levels[i] = 1
+    sc.irradiance = ob.ptr(irr); sc.irr_size = 1
+    sc.prefilter = ob.ptr(pre); sc.pre_size = 1; sc.pre_levels = 1
+    sc.lut_f16 = ob.ptr(lut); sc.lut_size = 2
+    sc.skybox = ob.ptr(sky); sc.sky_size = 1
+    u = _identity_uniforms()
+    proj = np.zeros(16, np.float32)
+    lib.orc_mat4_perspective(fov, W / H, near, far, ob.ptr(proj))
+    u.projection[:] = [float(x) for x in proj]
+    u.view[:] = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, -5, 1]                       # lookAt from (0, 0, 5)
+    u.view_pos[:] = [0, 0, 5, 0]
+    lights = [(10.0, 10.0, 10.0), (-10.0, 10.0, 10.0), (10.0, -10.0, 10.0), (-10.0, -10.0, 10.0)]
+    for i, lp in enumerate(lights):
+        u.light_pos[i][:] = [lp[0], lp[1], lp[2], 0.0]; u.light_color[i][:] = [300.0, 300.0, 300.0, 0.0]
+    emissive_factor = np.array([1.0, 0.5, 0.25])
+    u.emissive_factor[:] = [1.0, 0.5, 0.25, 0.0]
+    u.sampler_index = 15; u.use_mipmaps = 1
+    rgba = np.zeros((H, W, 4), np.uint8); vis = np.zeros((H, W), np.uint32)
+    lib.orc_draw_frame(C.byref(sc), C.byref(u), W, H, 0, H, ob.ptr(rgba), ob.ptr(vis))
+    assert (vis > 0).mean() > 0.25
+
+    def srgb(b):
+        c = np.asarray(b, np.float64) / 255.0
+        return np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4)
+    albedo = srgb(texel["albedo"][:3]); emissive = srgb(texel["emissive"][:3]) * emissive_factor
+    tn = np.asarray(texel["normal"][:3], np.float64) / 255.0 * 2.0 - 1.0
+    roughness, metalness = texel["mr"][1] / 255.0, texel["mr"][2] / 255.0
+    occlusion = texel["occlusion"][0] / 255.0
+    lut_a, lut_b = float(np.float16(lut_c[0])), float(np.float16(lut_c[1]))
+    th = math.tan(fov / 2)
+    norm = lambda a: a / np.linalg.norm(a)
+    PI = 3.14159265359
+
+    def world(px, py):   # the ray through the pixel centre meets the plane z = 0
+        xn, yn = (px + 0.5) / W * 2 - 1, 1 - (py + 0.5) / H * 2
+        return np.array([5 * xn * th * W / H, 5 * yn * th, 0.0])
+    uv_of = lambda p: np.array([(p[0] + 1.5) / 3.0, (1.5 - p[1]) / 3.0])
+
+    def ggx(c, rough):
+        k = (rough + 1.0) ** 2 / 8.0
+        return c / (c * (1.0 - k) + k)
+
+    worst, off = 0, 0
+    for y in range(H):
+        for x in range(W):
+            if not vis[y, x]:
+                continue
+            x0, y0 = x & ~1, y & ~1
+            p00, p10, p01 = world(x0, y0), world(x0 + 1, y0), world(x0, y0 + 1)
+            q1, q2 = p10 - p00, p01 - p00
+            st1, st2 = uv_of(p10) - uv_of(p00), uv_of(p01) - uv_of(p00)
+            pos = world(x, y)
+            N = np.array([0.0, 0.0, 1.0])
+            T = norm(q1 * st2[1] - q2 * st1[1])
+            B = -norm(np.cross(N, T))
+            normal = norm(T * tn[0] + B * tn[1] + N * tn[2])
+            view_dir = norm(eye - pos)
+            f0 = 0.04 * (1 - metalness) + albedo * metalness
+            Lo = np.zeros(3)
+            for lp in lights:
+                to_light = np.asarray(lp) - pos
+                light_dir = norm(to_light); halfway = norm(view_dir + light_dir)
+                radiance = 300.0 / float(to_light @ to_light)
+                a2 = (roughness * roughness) ** 2
+                ndoth = max(float(normal @ halfway), 0.0)
+                D = a2 / (PI * (ndoth * ndoth * (a2 - 1.0) + 1.0) ** 2)
+                F = f0 + (1.0 - f0) * min(max(1.0 - max(float(halfway @ view_dir), 0.0), 0.0), 1.0) ** 5
+                ndotv, ndotl = max(float(normal @ view_dir), 0.0), max(float(normal @ light_dir), 0.0)
+                G = ggx(ndotv, roughness) * ggx(ndotl, roughness)
+                kD = (1.0 - F) * (1.0 - metalness)
+                spec = D * F * G / (4.0 * ndotv * ndotl + 0.001)
+                Lo += (kD * albedo / PI + spec) * radiance * ndotl
+            ndotv = max(float(normal @ view_dir), 0.0)
+            kS = f0 + (np.maximum(1.0 - roughness, f0) - f0) * min(max(1.0 - ndotv, 0.0), 1.0) ** 5
+            kD = (1.0 - kS) * (1.0 - metalness)
+            ambient = (kD * irr_c[:3].astype(np.float64) * albedo + pre_c[:3].astype(np.float64) * (kS * lut_a + lut_b)) * occlusion
+            color = (ambient + Lo + emissive) ** (1.0 / 2.2)
+            want = np.rint(np.clip(color, 0.0, 1.0) * 255.0).astype(int)
+            d = int(np.abs(want - rgba[y, x, :3].astype(int)).max())
+            worst = max(worst, d); off += d > 0
+    assert worst <= 1 and off <= 0.02 * (vis > 0).sum(), (worst, off)
