@@ -448,3 +448,96 @@ def test_fragment_shading_matches_a_float64_evaluation():
             d = int(np.abs(want - rgba[y, x, :3].astype(int)).max())
             worst = max(worst, d); off += d > 0
     assert worst <= 1 and off <= 0.02 * (vis > 0).sum(), (worst, off)
+
+
+# ---- samplers ----
+def _sample2d(chain, w, h, levels, srgb, sampler, u, v, ddx=(0.0, 0.0), ddy=(0.0, 0.0)):
+    out = np.zeros(4, np.float32)
+    ob.load().orc_sample_2d_rgba8(ob.ptr(chain), w, h, levels, 1 if srgb else 0, sampler, u, v, ob.ptr(np.float32(ddx)), ob.ptr(np.float32(ddy)), ob.ptr(out))
+    return out.astype(np.float64)
+
+
+def test_material_sampler_filters_wraps_and_picks_levels():
+    """The sampler of renderer.ts:822-859 on a small texture: texel addressing, bilinear weights, repeat against
+    clamp-to-edge, magFilter / minFilter chosen by the footprint, mipmapFilter "nearest" switching level at
+    lambda = 0.5, and the sRGB decode of the *-srgb formats."""
+    rng = np.random.default_rng(7)
+    w, h = 8, 4
+    img = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    chain, levels = ob.mip_chain_rgba8(img, False)
+    assert levels == 4
+    f = img.astype(np.float64) / 255.0
+    REP, MAG, MIN = 3, 4, 8
+    centre = lambda i, j: ((i + 0.5) / w, (j + 0.5) / h)
+    for i, j in ((0, 0), (5, 2), (7, 3)):
+        for sampler in (0, REP, MAG | MIN, REP | MAG | MIN):
+            np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, sampler, *centre(i, j)), f[j, i], atol=1e-6)
+    # halfway between two texel centres: the mean with linear filtering, the right-hand texel with nearest
+    u, v = 3.0 / w, 1.5 / h
+    np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, MAG | MIN, u, v), 0.5 * (f[1, 2] + f[1, 3]), atol=1e-6)
+    np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, 0, u, v), f[1, 3], atol=1e-6)
+    # a general point: bilinear weights
+    u, v = (2.5 + 0.3) / w, (1.5 + 0.8) / h
+    want = (f[1, 2] * 0.7 + f[1, 3] * 0.3) * 0.2 + (f[2, 2] * 0.7 + f[2, 3] * 0.3) * 0.8
+    np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, MAG | MIN, u, v), want, atol=1e-6)
+    # the left border: repeat blends the last and the first column, clamp-to-edge stays on the first
+    np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, REP | MAG | MIN, 0.0, 0.5 / h), 0.5 * (f[0, 7] + f[0, 0]), atol=1e-6)
+    np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, MAG | MIN, 0.0, 0.5 / h), f[0, 0], atol=1e-6)
+    np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, REP, 1.0 + 0.5 / w, 2.0 + 1.5 / h), f[1, 0], atol=1e-6)
+    np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, 0, 1.7, -0.3), f[0, 7], atol=1e-6)
+    # footprint: rho texels per pixel along x.  rho < 1 magnifies (magFilter), rho > 1 minifies (minFilter)
+    u, v = 3.0 / w, 1.5 / h
+    lin, near_ = 0.5 * (f[1, 2] + f[1, 3]), f[1, 3]
+    for sampler, small, large in ((MAG, lin, near_), (MIN, near_, lin)):
+        np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, sampler, u, v, (0.5 / w, 0), (0, 0.5 / h)), small, atol=1e-6)
+        np.testing.assert_allclose(_sample2d(chain, w, h, 1, False, sampler, u, v, (1.2 / w, 0), (0, 0.5 / h)), large, atol=1e-6)
+    # mip level: nearest level of lambda = log2(rho); 1.40 -> level 0, 1.43 -> level 1, 2.8 -> 1, 2.9 -> 2 (sqrt 2 and 2 sqrt 2)
+    l1, l2 = ob.chain_level(chain, w, h, 1).astype(np.float64) / 255.0, ob.chain_level(chain, w, h, 2).astype(np.float64) / 255.0
+    box = np.floor((img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2]) / 4.0 + 0.5) / 255.0
+    np.testing.assert_allclose(l1, box, atol=1e-9)                      # rgba8 levels are stored rounded to nearest
+    u, v = 2.5 / w, 1.5 / h                                              # centre of level-0 texel (2, 1), inside level-1 texel (1, 0), level-2 texel (0, 0)
+    for rho, want in ((1.40, f[1, 2]), (1.43, l1[0, 1]), (2.8, l1[0, 1]), (2.9, l2[0, 0])):
+        np.testing.assert_allclose(_sample2d(chain, w, h, levels, False, 0, u, v, (rho / w, 0), (0, 0.1 / h)), want, atol=1e-6, err_msg=str(rho))
+    np.testing.assert_allclose(_sample2d(chain, w, h, levels, False, 0, u, v, (0, 0.1 / h), (0, 2.9 / h)), l2[0, 0], atol=1e-6)   # the larger axis counts
+    np.testing.assert_allclose(_sample2d(chain, w, h, levels, False, 0, u, v, (1000.0, 0), (0, 0)), ob.chain_level(chain, w, h, 3)[0, 0] / 255.0, atol=1e-6)
+    # sRGB formats decode before filtering (alpha stays linear)
+    s = _sample2d(chain, w, h, 1, True, 0, *centre(5, 2))
+    c = f[2, 5, :3]
+    np.testing.assert_allclose(s[:3], np.where(c <= 0.04045, c / 12.92, ((c + 0.055) / 1.055) ** 2.4), atol=1e-6)
+    assert abs(s[3] - f[2, 5, 3]) < 1e-6
+
+
+def test_cube_sampler_faces_seams_and_levels():
+    """Cube lookups (shader.wgsl:145, :149; skybox.wgsl:29): face selection and face coordinates of the Vulkan / WebGPU
+    table, bilinear taps that cross an edge onto the neighbouring face, the three-texel mean at a corner, and
+    the blend of two levels."""
+    n = 4
+    rng = np.random.default_rng(11)
+    l0, l1 = rng.random((6, n, n, 4)).astype(np.float32), rng.random((6, n // 2, n // 2, 4)).astype(np.float32)
+    chain = np.concatenate([l0.reshape(-1), l1.reshape(-1)])
+
+    def sample(d, lod=0.0, levels=2):
+        out = np.zeros(4, np.float32)
+        ob.load().orc_sample_cube(ob.ptr(chain), n, levels, ob.ptr(np.float32(d)), lod, ob.ptr(out))
+        return out.astype(np.float64)
+    # major axis -> face; at the face centre the four middle texels blend equally
+    for face, axis in enumerate([(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]):
+        np.testing.assert_allclose(sample(axis), l0[face, 1:3, 1:3].reshape(4, 4).mean(0), atol=1e-6)
+    # texel centres of each face: direction from (sc, tc) by the table's inverse
+    inv = [lambda s, t: (1, -t, -s), lambda s, t: (-1, -t, s), lambda s, t: (s, 1, t), lambda s, t: (s, -1, -t), lambda s, t: (s, -t, 1), lambda s, t: (-s, -t, -1)]
+    for face in range(6):
+        for i, j in ((0, 0), (3, 1), (2, 3)):
+            sc, tc = (i + 0.5) / n * 2 - 1, (j + 0.5) / n * 2 - 1
+            d = np.array(inv[face](sc, tc), np.float64) * 3.7                    # any positive scale
+            np.testing.assert_allclose(sample(d), l0[face, j, i], atol=1e-6)
+    # on the edge between +X and +Z, at a texel row's centre: half of each face's edge texel
+    for j in range(n):
+        tc = (j + 0.5) / n * 2 - 1
+        np.testing.assert_allclose(sample((1.0, -tc, 1.0)), 0.5 * (l0[0, j, 0] + l0[4, j, n - 1]), atol=1e-6)
+    # the corner (1, 1, 1): the mean of the three texels that meet there
+    np.testing.assert_allclose(sample((1.0, 1.0, 1.0)), (l0[0, 0, 0] + l0[2, n - 1, n - 1] + l0[4, 0, n - 1]) / 3.0, atol=1e-6)
+    # between levels: linear blend; beyond the last level: the last level
+    a, b = sample((0.3, -0.2, 1.0), 0.0), sample((0.3, -0.2, 1.0), 1.0)
+    np.testing.assert_allclose(sample((0.3, -0.2, 1.0), 0.25), 0.75 * a + 0.25 * b, atol=1e-6)
+    np.testing.assert_allclose(sample((0.3, -0.2, 1.0), 7.0), b, atol=1e-6)
+    np.testing.assert_allclose(sample((0, 0, 1), 1.0), l1[4].reshape(4, 4).mean(0), atol=1e-6)
