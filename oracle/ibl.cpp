@@ -50,11 +50,14 @@ inline V3 texel_direction(int gx, int gy, int gz, int size) {
 
 // equirectangular.wgsl:68-69: truncating equirect pixel of a direction in a w x h level.
 // textureLoad outside the level is implementation-defined in WGSL; it cannot happen for unit
-// vectors (max eqUV is below 1) and is clamped here.
+// vectors (max eqUV is below 1) and is clamped here.  A NaN direction converts to pixel 0 (the
+// float -> int conversion of NaN is implementation-defined in WGSL; 0 is what the gfx950 conversion
+// gives): it occurs at the centre texel of the +-Y irradiance faces of an even-sized map, where
+// irradiancemap.wgsl:69-70 normalises cross(up, N) = 0.
 inline void equirect_pixel(V3 d, int w, int h, int* px, int* py) {
   float u = std::atan2(d.z, d.x) * INV_ATAN_X + 0.5f;
   float v = std::asin(d.y) * INV_ATAN_Y + 0.5f;
-  int x = (int)(u * (float)w), y = (int)(v * (float)h);
+  int x = u == u ? (int)(u * (float)w) : 0, y = v == v ? (int)(v * (float)h) : 0;
   *px = std::min(std::max(x, 0), w - 1);
   *py = std::min(std::max(y, 0), h - 1);
 }

@@ -64,7 +64,12 @@ def test_ibl_maps_match_oracle(small):
     lib, r, m = small.pkg._lib, small.renderer, small.oracle.maps()
     sky = r.download_map(lib.MAP_SKYBOX)
     assert (sky == m["sky"]).all(axis=-1).mean() >= 0.9999           # texel copies: exact unless the source pixel flips
-    assert_map_close(r.download_map(lib.MAP_IRRADIANCE), m["irr"], "irradiance", share=2e-3)
+    irr = r.download_map(lib.MAP_IRRADIANCE)
+    assert_map_close(irr, m["irr"], "irradiance", share=2e-3)
+    # the centre texel of the +-Y faces: the shader's tangent frame is 0/0 there and every tap reads equirect pixel (0, 0)
+    for face in (2, 3):
+        np.testing.assert_allclose(irr[face, 8, 8, :3], m["irr"][face, 8, 8, :3], rtol=1e-3)
+        np.testing.assert_allclose(irr[face, 8, 8, :3], small.oracle.hdr_data.reshape(-1, 4)[0, :3] * m["irr"][face, 8, 8, 0] / small.oracle.hdr_data[0], rtol=1e-5)
     for lvl in range(5):
         assert_map_close(r.download_map(lib.MAP_PREFILTER, lvl), m["pre"][lvl], f"prefilter level {lvl}")
     lut = r.download_map(lib.MAP_BRDF_LUT).view(np.float16).astype(np.float32)

@@ -124,6 +124,37 @@ def test_irradiance_constant_environment():
     np.testing.assert_allclose(irr[..., 2], 0.5 * want, rtol=1e-4)
 
 
+def test_irradiance_of_a_linear_environment():
+    """A radiance field L(d) = 1 + a.d convolves to 1 + (2/3) a.N under the shader's normalisation (PI * sum / count
+    with weights cos t sin t): checks the face table and cube coordinates that give N (irradiancemap.wgsl:21-67), the
+    hemisphere centred on N, and the direction -> equirect pixel mapping (:82-83), for every face."""
+    w, h, size = 1024, 512, 4
+    a = np.array([0.3, -0.5, 0.4])
+    u, v = (np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h
+    phi, lat = (u - 0.5) / 0.1591, (v - 0.5) / 0.3183                        # inverse of eqUV = (atan2(z, x), asin(y)) * invAtan + 0.5
+    d = np.stack([np.cos(lat)[:, None] * np.cos(phi)[None, :], np.broadcast_to(np.sin(lat)[:, None], (h, w)), np.cos(lat)[:, None] * np.sin(phi)[None, :]], -1)
+    hdr = np.ones((h, w, 4), np.float32)
+    hdr[..., 0] = 1.0 + d @ a
+    hdr[..., 1] = 1.0 - 0.5 * (d @ a)
+    irr = ob.irradiance(hdr.reshape(-1), w, h, size)
+    faces = [((1, 0, 0), (0, 1, 0), (0, 0, -1)), ((-1, 0, 0), (0, 1, 0), (0, 0, 1)), ((0, -1, 0), (0, 0, 1), (1, 0, 0)),
+             ((0, 1, 0), (0, 0, -1), (1, 0, 0)), ((0, 0, 1), (0, 1, 0), (1, 0, 0)), ((0, 0, -1), (0, 1, 0), (-1, 0, 0))]   # forward, up, right
+    for face, (fwd, up, right) in enumerate(faces):
+        for gy in range(size):
+            for gx in range(size):
+                cx, cy = gx / size * 2 - 1, gy / size * 2 - 1             # no half-texel offset in the shader
+                n = np.array(fwd, float) + np.array(right, float) * cx + np.array(up, float) * cy
+                n /= np.linalg.norm(n)
+                if abs(n[1]) == 1.0:
+                    # N parallel to the shader's fixed up vector: cross(up, N) = 0, the tangent frame and every sample direction
+                    # are NaN, and all taps read equirect pixel (0, 0) (the one implementation-defined texel of the map)
+                    assert abs(irr[face, gy, gx, 0] - hdr[0, 0, 0]) < 0.02 and face in (2, 3) and (gx, gy) == (size // 2, size // 2)
+                    continue
+                assert abs(irr[face, gy, gx, 0] - (1 + 2 / 3 * (a @ n))) < 0.02, (face, gx, gy)
+                assert abs(irr[face, gy, gx, 1] - (1 - 1 / 3 * (a @ n))) < 0.02, (face, gx, gy)
+                assert abs(irr[face, gy, gx, 2] - 1.0) < 0.01
+
+
 def test_brdf_lut_quirks():
     """brdf.wgsl:67-106: column 0 (NdotV = 0) is 0/0 = NaN; row y holds roughness (size-y)/(size-1);
     the last row/column entry is finite with A + B <= 1."""
