@@ -109,6 +109,69 @@ def test_prefilter_constant_environment_is_constant():
         np.testing.assert_allclose(pre[..., :3], np.broadcast_to([0.5, 1.5, 2.5], pre[..., :3].shape), rtol=2e-5)
 
 
+def test_prefilter_matches_a_float64_evaluation():
+    """prefiltermap.wgsl:70-171 written again in float64 numpy (Hammersley points, GGX importance sampling with its
+    tangent frame and the |N.z| >= 0.999 branch, pdf-driven source level with the 512^2 constant, two-level blend,
+    N.L weighting) on a smooth environment, for texels of every face and three roughness values."""
+    w, h, size = 256, 128, 4
+    u, v = (np.arange(w) + 0.5) / w, (np.arange(h) + 0.5) / h
+    phi, lat = (u - 0.5) / 0.1591, (v - 0.5) / 0.3183
+    d = np.stack([np.cos(lat)[:, None] * np.cos(phi)[None, :], np.broadcast_to(np.sin(lat)[:, None], (h, w)), np.cos(lat)[:, None] * np.sin(phi)[None, :]], -1)
+    hdr = np.ones((h, w, 4), np.float32)
+    hdr[..., 0] = 1.5 + d @ np.array([0.5, 0.7, -0.4]); hdr[..., 1] = 2.0 + np.sin(3.0 * d[..., 0]) * d[..., 1]; hdr[..., 2] = 0.2 + d[..., 2] ** 2
+    chain, levels = ob.mip_chain_rgba32f(hdr.reshape(-1), w, h)
+    level = [ob.chain_level(chain, w, h, l).astype(np.float64) for l in range(levels)]
+    PI = 3.14159265359
+    faces = [((1, 0, 0), (0, 1, 0), (0, 0, -1)), ((-1, 0, 0), (0, 1, 0), (0, 0, 1)), ((0, -1, 0), (0, 0, 1), (1, 0, 0)),
+             ((0, 1, 0), (0, 0, -1), (1, 0, 0)), ((0, 0, 1), (0, 1, 0), (1, 0, 0)), ((0, 0, -1), (0, 1, 0), (-1, 0, 0))]   # forward, up, right
+    i = np.arange(1024, dtype=np.uint64)
+    bits = np.zeros(1024, np.uint64)
+    for b in range(32):
+        bits |= ((i >> np.uint64(b)) & np.uint64(1)) << np.uint64(31 - b)              # bit reversal
+    xi = np.stack([i / 1024.0, bits * 2.3283064365386963e-10], 1)
+
+    def texel_of(L, l):
+        l = min(max(l, 0), levels - 1)                                                  # a level outside the chain is clamped into it
+        lw, lh = max(1, w >> l), max(1, h >> l)
+        eu, ev = math.atan2(L[2], L[0]) * 0.1591 + 0.5, math.asin(min(max(L[1], -1.0), 1.0)) * 0.3183 + 0.5
+        return level[l][min(int(ev * lh), lh - 1), min(int(eu * lw), lw - 1), :3]
+
+    def prefilter(face, gx, gy, rough):
+        fwd, up_, right = (np.array(a, float) for a in faces[face])
+        N = fwd + right * (gx / size * 2 - 1) + up_ * (gy / size * 2 - 1)
+        N /= np.linalg.norm(N)
+        a = rough * rough
+        up = np.array([0.0, 0.0, 1.0]) if abs(N[2]) < 0.999 else np.array([1.0, 0.0, 0.0])
+        tangent = np.cross(up, N); tangent /= np.linalg.norm(tangent)
+        bitangent = np.cross(N, tangent)
+        color, total = np.zeros(3), 0.0
+        for x0, x1 in xi:
+            ph = 2.0 * PI * x0
+            ct = math.sqrt((1.0 - x1) / (1.0 + (a * a - 1.0) * x1)); st = math.sqrt(max(1.0 - ct * ct, 0.0))
+            H = tangent * (math.cos(ph) * st) + bitangent * (math.sin(ph) * st) + N * ct
+            H /= np.linalg.norm(H)
+            L = 2.0 * (N @ H) * H - N
+            L /= np.linalg.norm(L)
+            ndotl = max(float(N @ L), 0.0)
+            if ndotl <= 0.0:
+                continue
+            ndoth = max(float(N @ H), 0.0)
+            D = a * a / (PI * (ndoth * ndoth * (a * a - 1.0) + 1.0) ** 2)
+            pdf = D * ndoth / (4.0 * ndoth) + 0.0001                                     # V = N: H.V = N.H
+            sa_texel, sa_sample = 4.0 * PI / (6.0 * 512.0 * 512.0), 1.0 / (1024.0 * pdf + 0.0001)
+            mip = 0.0 if rough == 0.0 else 0.5 * math.log2(sa_sample / sa_texel)
+            m0 = math.floor(mip); f = mip - m0
+            color += (texel_of(L, m0) * (1.0 - f) + texel_of(L, m0 + 1) * f) * ndotl
+            total += ndotl
+        return color / total
+
+    for rough in (0.25, 0.6, 1.0):
+        got = ob.prefilter_level(chain, w, h, levels, size, np.float32(rough))
+        for face, gx, gy in ((0, 1, 3), (1, 0, 0), (2, 3, 1), (3, 2, 2), (4, 2, 2), (5, 1, 2)):
+            want = prefilter(face, gx, gy, float(np.float32(rough)))
+            np.testing.assert_allclose(got[face, gy, gx, :3], want, rtol=2e-3, err_msg=f"roughness {rough} face {face} texel ({gx},{gy})")
+
+
 def test_irradiance_constant_environment():
     # irradiancemap.wgsl:75-88: PI * L * sum(cos t sin t) / N over the 252 x 63 grid
     w, h, size = 64, 32, 2
