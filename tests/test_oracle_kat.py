@@ -635,3 +635,55 @@ def test_cube_sampler_faces_seams_and_levels():
     np.testing.assert_allclose(sample((0.3, -0.2, 1.0), 0.25), 0.75 * a + 0.25 * b, atol=1e-6)
     np.testing.assert_allclose(sample((0.3, -0.2, 1.0), 7.0), b, atol=1e-6)
     np.testing.assert_allclose(sample((0, 0, 1), 1.0), l1[4].reshape(4, 4).mean(0), atol=1e-6)
+
+
+def test_skybox_pass_matches_a_float64_evaluation():
+    """skybox.wgsl:13-33 and the draw of renderer.ts:2008-2011 on a frame without geometry: pixel centre -> clip
+    position (z = w = 1) -> inverse view-projection -> direction with z negated -> bilinear cube lookup -> gamma,
+    evaluated again in float64 for every pixel whose four taps lie inside one face."""
+    lib = ob.load()
+    W, H, n = 96, 54, 32
+    rng = np.random.default_rng(3)
+    sky = (rng.random((6, n, n, 4)) * 1.2).astype(np.float32)
+    sky[..., 3] = 1.0
+    proj, view, pv, inv = (np.zeros(16, np.float32) for _ in range(4))
+    lib.orc_mat4_perspective(math.radians(45.0), W / H, 1.0, 100.0, ob.ptr(proj))
+    eye, target, up = np.float32([3.0, 2.0, 4.0]), np.float32([0.2, -0.1, 0.0]), np.float32([0, 1, 0])
+    lib.orc_mat4_look_at(ob.ptr(eye), ob.ptr(target), ob.ptr(up), ob.ptr(view))
+    lib.orc_mat4_mul(ob.ptr(proj), ob.ptr(view), ob.ptr(pv))
+    lib.orc_mat4_inverse(ob.ptr(pv), ob.ptr(inv))
+    np.testing.assert_allclose((pv.astype(np.float64).reshape(4, 4).T @ inv.astype(np.float64).reshape(4, 4).T), np.eye(4), atol=1e-4)
+    v = np.zeros((3, 8), np.float32)
+    v[:, :3] = [(50, 50, 50), (51, 50, 50), (50, 51, 50)]                               # a triangle far outside the view: nothing is covered
+    sc = _tiny_scene(v, np.array([0, 1, 2], np.uint16))
+    sc.skybox = ob.ptr(sky); sc.sky_size = n
+    u = _identity_uniforms()
+    u.view[:] = [float(x) for x in view]; u.projection[:] = [float(x) for x in proj]; u.inv_view_proj[:] = [float(x) for x in inv]
+    rgba = np.zeros((H, W, 4), np.uint8); vis = np.zeros((H, W), np.uint32)
+    lib.orc_draw_frame(C.byref(sc), C.byref(u), W, H, 0, H, ob.ptr(rgba), ob.ptr(vis))
+    assert (vis == 0).all()
+    M = inv.astype(np.float64).reshape(4, 4).T                                           # column-major storage
+    table = [lambda d: (-d[2], -d[1], d[0]), lambda d: (d[2], -d[1], d[0]), lambda d: (d[0], d[2], d[1]),
+             lambda d: (d[0], -d[2], d[1]), lambda d: (d[0], -d[1], d[2]), lambda d: (-d[0], -d[1], d[2])]   # (sc, tc, ma) per face
+    checked, worst, off = 0, 0, 0
+    for y in range(H):
+        for x in range(W):
+            clip = np.array([(x + 0.5) / W * 2 - 1, 1 - (y + 0.5) / H * 2, 1.0, 1.0])
+            t = M @ clip
+            d = t[:3] / t[3]
+            d = d / np.linalg.norm(d) * np.array([1.0, 1.0, -1.0])
+            ax = np.abs(d)
+            face = (4 if d[2] >= 0 else 5) if ax[2] >= ax[0] and ax[2] >= ax[1] else (2 if d[1] >= 0 else 3) if ax[1] >= ax[0] else (0 if d[0] >= 0 else 1)
+            s_, t_, ma = table[face](d)
+            fu, fv = (0.5 * s_ / abs(ma) + 0.5) * n - 0.5, (0.5 * t_ / abs(ma) + 0.5) * n - 0.5
+            i0, j0 = math.floor(fu), math.floor(fv)
+            if i0 < 0 or j0 < 0 or i0 + 1 >= n or j0 + 1 >= n:
+                continue
+            a, b = fu - i0, fv - j0
+            f = sky[face].astype(np.float64)
+            c = (f[j0, i0] * (1 - a) + f[j0, i0 + 1] * a) * (1 - b) + (f[j0 + 1, i0] * (1 - a) + f[j0 + 1, i0 + 1] * a) * b
+            want = np.rint(np.clip(c[:3] ** (1 / 2.2), 0, 1) * 255).astype(int)
+            dd = int(np.abs(want - rgba[y, x, :3].astype(int)).max())
+            worst = max(worst, dd); off += dd > 0; checked += 1
+    assert checked > 0.9 * W * H and worst <= 1 and off < 0.01 * checked, (checked, worst, off)
+    assert (rgba[..., 3] == 255).all()
