@@ -439,15 +439,22 @@ def test_raster_clips_against_the_near_plane():
 
 
 # ---- fs_main against an independent float64 evaluation ----
-def test_fragment_shading_matches_a_float64_evaluation():
-    """shader.wgsl:93-160 evaluated in float64 numpy, written from the WGSL alone, for a scene where every lookup is a
-    constant (1x1 material textures, one-texel cube maps, a flat BRDF table): the oracle's f32 frame must agree to
-    the last 8-bit step on (almost) every pixel.  Pins the TBN construction, the four-light Cook-Torrance loop, the
-    split-sum ambient term, the sRGB decode of the colour textures and the gamma curve."""
+@pytest.mark.parametrize("turn_deg,shift", [(0.0, (0.0, 0.0, 0.0)), (50.0, (0.3, -0.2, 0.5)), (-35.0, (-0.4, 0.1, -1.0))])
+def test_fragment_shading_matches_a_float64_evaluation(turn_deg, shift):
+    """shader.wgsl:37-47, :93-160 evaluated in float64 numpy, written from the WGSL alone, for a scene where every lookup
+    is a constant (1x1 material textures, one-texel cube maps, a flat BRDF table): the oracle's f32 frame must agree
+    to the last 8-bit step on (almost) every pixel.  A quad in a plane: the varyings of a pixel follow from where the
+    ray through the pixel centre meets the plane, which pins perspective-correct interpolation when the plane is
+    turned away from the camera, the model / normal matrices, the coarse derivatives and the TBN construction,
+    the four-light Cook-Torrance loop, the split-sum ambient term, the sRGB decode and the gamma curve."""
     lib = ob.load()
     W, H = 64, 36
     fov, near, far = math.radians(45.0), 1.0, 100.0
     eye = np.array([0.0, 0.0, 5.0])
+    ca, sa = math.cos(math.radians(turn_deg)), math.sin(math.radians(turn_deg))
+    R = np.array([[ca, 0, sa], [0, 1, 0], [-sa, 0, ca]])                                 # about +y
+    P0 = np.array(shift, float)
+    model = np.eye(4); model[:3, :3] = R; model[:3, 3] = P0
     quad = np.float32([[-1.5, -1.5, 0], [1.5, -1.5, 0], [1.5, 1.5, 0], [-1.5, 1.5, 0]])
     v = np.zeros((4, 8), np.float32)
     v[:, :3] = quad
@@ -471,6 +478,8 @@ def test_fragment_shading_matches_a_float64_evaluation():
     lib.orc_mat4_perspective(fov, W / H, near, far, ob.ptr(proj))
     u.projection[:] = [float(x) for x in proj]
     u.view[:] = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, -5, 1]                       # lookAt from (0, 0, 5)
+    u.model[:] = [float(x) for x in model.T.reshape(-1)]                                 # column-major
+    u.normal[:] = [float(x) for x in np.linalg.inv(model).reshape(-1)]                   # transpose(inverse(model)), renderer.ts:1837, column-major
     u.view_pos[:] = [0, 0, 5, 0]
     lights = [(10.0, 10.0, 10.0), (-10.0, 10.0, 10.0), (10.0, -10.0, 10.0), (-10.0, -10.0, 10.0)]
     for i, lp in enumerate(lights):
@@ -480,7 +489,7 @@ def test_fragment_shading_matches_a_float64_evaluation():
     u.sampler_index = 15; u.use_mipmaps = 1
     rgba = np.zeros((H, W, 4), np.uint8); vis = np.zeros((H, W), np.uint32)
     lib.orc_draw_frame(C.byref(sc), C.byref(u), W, H, 0, H, ob.ptr(rgba), ob.ptr(vis))
-    assert (vis > 0).mean() > 0.25
+    assert (vis > 0).mean() > 0.12
 
     def srgb(b):
         c = np.asarray(b, np.float64) / 255.0
@@ -493,11 +502,16 @@ def test_fragment_shading_matches_a_float64_evaluation():
     th = math.tan(fov / 2)
     norm = lambda a: a / np.linalg.norm(a)
     PI = 3.14159265359
+    N = R @ np.array([0.0, 0.0, 1.0])
 
-    def world(px, py):   # the ray through the pixel centre meets the plane z = 0
+    def world(px, py):   # the ray through the pixel centre meets the quad's plane
         xn, yn = (px + 0.5) / W * 2 - 1, 1 - (py + 0.5) / H * 2
-        return np.array([5 * xn * th * W / H, 5 * yn * th, 0.0])
-    uv_of = lambda p: np.array([(p[0] + 1.5) / 3.0, (1.5 - p[1]) / 3.0])
+        ray = np.array([xn * th * W / H, yn * th, -1.0])
+        return eye + ray * (((P0 - eye) @ N) / (ray @ N))
+
+    def uv_of(p):
+        local = R.T @ (p - P0)
+        return np.array([(local[0] + 1.5) / 3.0, (1.5 - local[1]) / 3.0])
 
     def ggx(c, rough):
         k = (rough + 1.0) ** 2 / 8.0
@@ -513,7 +527,6 @@ def test_fragment_shading_matches_a_float64_evaluation():
             q1, q2 = p10 - p00, p01 - p00
             st1, st2 = uv_of(p10) - uv_of(p00), uv_of(p01) - uv_of(p00)
             pos = world(x, y)
-            N = np.array([0.0, 0.0, 1.0])
             T = norm(q1 * st2[1] - q2 * st1[1])
             B = -norm(np.cross(N, T))
             normal = norm(T * tn[0] + B * tn[1] + N * tn[2])
@@ -541,7 +554,7 @@ def test_fragment_shading_matches_a_float64_evaluation():
             want = np.rint(np.clip(color, 0.0, 1.0) * 255.0).astype(int)
             d = int(np.abs(want - rgba[y, x, :3].astype(int)).max())
             worst = max(worst, d); off += d > 0
-    assert worst <= 1 and off <= 0.02 * (vis > 0).sum(), (worst, off)
+    assert worst <= 1 and off <= 0.03 * (vis > 0).sum(), (worst, off)
 
 
 # ---- samplers ----
