@@ -68,8 +68,8 @@ typedef struct PbrFrameUniforms {
 /* Per-frame timings (the reference's timestamp query, renderer.ts:1968-1974, :2040-2044) and
  * the coverage figure the bandwidth model needs.  Filling it synchronises the stream. */
 typedef struct PbrFrameStats {
-  float ms_vertex;      /* vertex transform kernel */
-  float ms_setup;       /* triangle setup + binning kernels */
+  float ms_vertex;      /* 0: the vertex transform runs inside the setup kernel (kept for layout compatibility) */
+  float ms_setup;       /* vertex transform + triangle setup + binning kernel */
   float ms_raster;      /* tile rasteriser */
   float ms_resolve;     /* deferred shading resolve */
   float ms_total;       /* first launch to last completion */

@@ -316,29 +316,24 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   const int n_tiles = tiles_x * tiles_y;
   static const float share_vertex = getenv("PBR_SKY_SHARE_VERTEX") ? (float)atof(getenv("PBR_SKY_SHARE_VERTEX")) : 0.15f;
   static const float share_setup = getenv("PBR_SKY_SHARE_SETUP") ? (float)atof(getenv("PBR_SKY_SHARE_SETUP")) : 0.40f;
-  SkyShare sky_a, sky_b;
-  sky_a.sky = pr->sky_b.cube; sky_a.rgba8 = reinterpret_cast<uint32_t*>(color); sky_a.first = 0; sky_a.own_blocks = 0;
-  // The specialised frame has no vertex launch: the setup kernel transforms each triangle's vertices from
-  // the streams itself.  The general-sampler resolve reads transformed vertices from memory, so that
-  // frame keeps the vertex launch.
-  // The multisampled resolve also reads transformed vertices, and blends over the skybox colour, which
-  // therefore has to be complete before the rasteriser: its tiles are split between the two launches before it.
-  const bool from_streams = fast && !msaa;
-  sky_a.count = from_streams ? 0 : (int)(n_tiles * share_vertex);
-  sky_b = sky_a; sky_b.first = sky_a.count;
-  sky_b.count = msaa ? n_tiles - sky_a.count : std::min(n_tiles - sky_a.count, (int)(n_tiles * (fast ? share_vertex + share_setup : share_setup)));
+  // A frame has no vertex launch: the setup kernel transforms each triangle's vertices from the streams itself
+  // and leaves a shading record per triangle, which is all the resolve kernels read.  (PBR_SKY_SHARE_VERTEX
+  // dates from a separate vertex launch; its tiles now ride in the setup launch as well.)
+  // The multisampled resolve blends over the skybox colour, which therefore has to be complete before the
+  // rasteriser: all its tiles ride in the setup launch.
+  SkyShare sky_b;
+  sky_b.sky = pr->sky_b.cube; sky_b.rgba8 = reinterpret_cast<uint32_t*>(color); sky_b.first = 0; sky_b.own_blocks = 0;
+  sky_b.count = msaa ? n_tiles : std::min(n_tiles, (int)(n_tiles * (share_vertex + share_setup)));
   const int sky_from_tile = sky_b.first + sky_b.count;
-  VertexSource source = {c->d_vout, nullptr, nullptr, nullptr};
-  if (from_streams) { source.vsoa = c->d_vsoa; source.inst_model = c->d_inst_model; source.inst_normal = c->d_inst_normal; }
-  else launch_vertex_stage(s, dp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances, sky_a);
+  const VertexSource source = {nullptr, c->d_vsoa, c->d_inst_model, c->d_inst_normal};
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
   launch_setup_and_bin(s, dp, source, c->d_indices, c->d_setup, c->d_records, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
                        (uint32_t)c->overflow_cap, counters, c->n_indices / 3, c->n_instances, sky_b);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
-  // the visibility buffer is only written when someone will read it: the caller (vis output), the
-  // coverage count of the statistics, or the general-sampler resolve
-  const bool write_vis = d_vis != nullptr || want_host_vis || timed || (!fast && !msaa);
+  // the visibility buffer is only written when someone will read it: the caller (vis output) or the
+  // coverage count of the statistics
+  const bool write_vis = d_vis != nullptr || want_host_vis || timed;
   if (msaa)
     launch_raster_msaa(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
                        counters, next_counters, c->d_tile_live, write_vis || c->capture_depth, tiles_x, tiles_y);

@@ -224,12 +224,6 @@ PBR_DEV Varyings blend(const Tri& t, float b0, float b1, float b2) {
   return v;
 }
 
-PBR_DEV void snap_xy(float4 c, int W, int H, int& X, int& Y) {
-  const float nx = div_rn(c.x, c.w), ny = div_rn(c.y, c.w);
-  X = __float2int_rn(mul_rn(mul_rn(mul_rn(add_rn(nx, 1.0f), 0.5f), (float)W), 256.0f));
-  Y = __float2int_rn(mul_rn(mul_rn(mul_rn(sub_rn(1.0f, ny), 0.5f), (float)H), 256.0f));
-}
-
 // Screen-space barycentrics of one triangle over one quad.  They come from the snapped vertices
 // through integer edge functions at the quad's first pixel centre; the other three centres are one
 // pixel step away, added in f32.
@@ -240,27 +234,31 @@ struct QuadBary {
   float iw0, iw1, iw2;          // 1 / w of the three vertices
 };
 
-PBR_DEV QuadBary quad_bary(const Tri& t, int qx, int qy, int W, int H) {
-  QuadBary b;
-  b.projective = t.c0.w > 0.0f && t.c1.w > 0.0f && t.c2.w > 0.0f && fabsf(t.c0.x) <= PBR_GUARD * t.c0.w && fabsf(t.c0.y) <= PBR_GUARD * t.c0.w &&
-                 fabsf(t.c1.x) <= PBR_GUARD * t.c1.w && fabsf(t.c1.y) <= PBR_GUARD * t.c1.w && fabsf(t.c2.x) <= PBR_GUARD * t.c2.w &&
-                 fabsf(t.c2.y) <= PBR_GUARD * t.c2.w;
-  if (b.projective) {
-    int X0, Y0, X1, Y1, X2, Y2;
-    snap_xy(t.c0, W, H, X0, Y0); snap_xy(t.c1, W, H, X1, Y1); snap_xy(t.c2, W, H, X2, Y2);
-    const long long area = (long long)(X1 - X0) * (Y2 - Y0) - (long long)(X2 - X0) * (Y1 - Y0);
-    if (area == 0) { b.projective = false; return b; }
+// The triangle a pixel shows, from the shading record the setup kernel wrote for it (one round of nine 16-byte
+// loads): attributes, and the barycentrics of quad (qx, qy) from the snapped vertices the rasteriser used.
+PBR_DEV void load_triangle(const ResolveInputs& in, uint32_t tri_index, int qx, int qy, Tri& t, QuadBary& qb) {
+  const float4* rec = reinterpret_cast<const float4*>(in.records + tri_index);
+  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7], r8 = rec[8];
+  t.p0 = v3(r3.x, r3.y, r3.z); t.p1 = v3(r3.w, r4.x, r4.y); t.p2 = v3(r4.z, r4.w, r5.x);
+  t.n0 = v3(r5.y, r5.z, r5.w); t.n1 = v3(r6.x, r6.y, r6.z); t.n2 = v3(r6.w, r7.x, r7.y);
+  t.t0 = make_float2(r7.z, r7.w); t.t1 = make_float2(r8.x, r8.y); t.t2 = make_float2(r8.z, r8.w);
+  qb.projective = __float_as_int(r1.w) != 0;
+  if (qb.projective) {
+    const int X0 = __float_as_int(r0.x), Y0 = __float_as_int(r0.y), X1 = __float_as_int(r0.z), Y1 = __float_as_int(r0.w), X2 = __float_as_int(r1.x),
+              Y2 = __float_as_int(r1.y);
     const long long px = (long long)qx * 256 + 128, py = (long long)qy * 256 + 128;
     const int a0 = -(Y2 - Y1), b0 = X2 - X1, a1 = -(Y0 - Y2), b1 = X0 - X2;
     const long long e0 = (long long)b0 * (py - Y1) + (long long)a0 * (px - X1);
     const long long e1 = (long long)b1 * (py - Y2) + (long long)a1 * (px - X2);
-    const float inv_area = rcp_fast((float)area);
-    b.l0 = (float)e0 * inv_area; b.l1 = (float)e1 * inv_area;
-    b.l0x = (float)(a0 * 256) * inv_area; b.l0y = (float)(b0 * 256) * inv_area;
-    b.l1x = (float)(a1 * 256) * inv_area; b.l1y = (float)(b1 * 256) * inv_area;
-    b.iw0 = rcp_fast(t.c0.w); b.iw1 = rcp_fast(t.c1.w); b.iw2 = rcp_fast(t.c2.w);
+    const float inv_area = r1.z;
+    qb.l0 = (float)e0 * inv_area; qb.l1 = (float)e1 * inv_area;
+    qb.l0x = (float)(a0 * 256) * inv_area; qb.l0y = (float)(b0 * 256) * inv_area;
+    qb.l1x = (float)(a1 * 256) * inv_area; qb.l1y = (float)(b1 * 256) * inv_area;
+    qb.iw0 = r2.x; qb.iw1 = r2.y; qb.iw2 = r2.z;
+  } else {
+    // a vertex behind the eye or beyond the guard band (rare): the homogeneous form needs the clip positions
+    t.c0 = rec[9]; t.c1 = rec[10]; t.c2 = rec[11];
   }
-  return b;
 }
 
 // Perspective-correct varyings at pixel (qx + dx, qy + dy), dx, dy in {0, 1}.
@@ -457,15 +455,7 @@ PBR_DEV uint32_t shade_quad_lane(const FrameParams* p, const ResolveInputs& in, 
   Tri t;
   QuadBary qb;
   if (id != 0u) {
-    uint32_t inst = 0, tri = id - 1u;
-    if (p->n_instances > 1) { inst = tri / (uint32_t)p->n_tris; tri -= inst * (uint32_t)p->n_tris; }
-    const VertexOut* vb = in.vout + (size_t)inst * p->n_verts;
-    const VertexOut v0 = vb[in.indices[3 * (size_t)tri]], v1 = vb[in.indices[3 * (size_t)tri + 1]], v2 = vb[in.indices[3 * (size_t)tri + 2]];
-    t.c0 = v0.clip; t.c1 = v1.clip; t.c2 = v2.clip;
-    t.p0 = v3(v0.world_u.x, v0.world_u.y, v0.world_u.z); t.p1 = v3(v1.world_u.x, v1.world_u.y, v1.world_u.z); t.p2 = v3(v2.world_u.x, v2.world_u.y, v2.world_u.z);
-    t.n0 = v3(v0.nrm_v.x, v0.nrm_v.y, v0.nrm_v.z); t.n1 = v3(v1.nrm_v.x, v1.nrm_v.y, v1.nrm_v.z); t.n2 = v3(v2.nrm_v.x, v2.nrm_v.y, v2.nrm_v.z);
-    t.t0 = make_float2(v0.world_u.w, v0.nrm_v.w); t.t1 = make_float2(v1.world_u.w, v1.nrm_v.w); t.t2 = make_float2(v2.world_u.w, v2.nrm_v.w);
-    qb = quad_bary(t, qx, qy, p->W, p->H);
+    load_triangle(in, id - 1u, qx, qy, t, qb);
     const Varyings h0 = varyings_at(t, qb, qx, qy, 0, 0, p->W, p->H), h1 = varyings_at(t, qb, qx, qy, 1, 0, p->W, p->H),
                    h2 = varyings_at(t, qb, qx, qy, 0, 1, p->W, p->H);
     f = sub == 0 ? h0 : sub == 1 ? h1 : sub == 2 ? h2 : varyings_at(t, qb, qx, qy, 1, 1, p->W, p->H);
@@ -506,27 +496,6 @@ PBR_DEV uint32_t shade_quad_lane(const FrameParams* p, const ResolveInputs& in, 
     color = shade_owned<FAST>(p, in, q, f, fc, fp, lambda, make_float2(lut1.x - lut0.x, lut1.y - lut0.y), make_float2(lut2.x - lut0.x, lut2.y - lut0.y), s_srgb);
   }
   return color;
-}
-
-// One thread per covered pixel; a wavefront covers 32 x 2 pixels, a workgroup 32 x 8.
-template <bool FAST>
-__global__ void __launch_bounds__(256) resolve_surface_kernel(const FrameParams frame_params, ResolveInputs in, const float* __restrict__ srgb_lut,
-                                                              const uint32_t* __restrict__ vis, uint32_t* __restrict__ rgba8) {
-  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
-  __shared__ float s_srgb[256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int sub = lane & 3, quad = lane >> 2;
-  const int qx = blockIdx.x * 32 + quad * 2, qy = p->y0 + blockIdx.y * 8 + wave * 2;
-  const int x = qx + (sub & 1), y = qy + (sub >> 1);
-  const bool live = x < p->W && y < p->y1;
-  const size_t o = live ? (size_t)(y - p->y0) * p->W + x : 0;
-  const uint32_t id = live ? vis[o] : 0u;
-  if (__syncthreads_or(id != 0u) == 0) return;   // nothing but background in this workgroup
-  s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
-  __syncthreads();
-  if (__ballot(id != 0u) == 0ull) return;
-  const uint32_t color = shade_quad_lane<FAST, false>(p, in, s_srgb, id, qx, qy, lane, sub);
-  if (id != 0u) rgba8[o] = color;
 }
 
 // The resolve of the multisampled pipeline.  vis holds the triangle of each of the pixel's four samples.
@@ -661,30 +630,9 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
 
   // first dependent load: the triangle's record (idle lanes read triangle 0; their results are unused)
   const uint32_t tri_id = cov ? id - 1u : 0u;
-  const float4* rec = reinterpret_cast<const float4*>(in.records + tri_id);
-  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7], r8 = rec[8];
   Tri t;
-  t.p0 = v3(r3.x, r3.y, r3.z); t.p1 = v3(r3.w, r4.x, r4.y); t.p2 = v3(r4.z, r4.w, r5.x);
-  t.n0 = v3(r5.y, r5.z, r5.w); t.n1 = v3(r6.x, r6.y, r6.z); t.n2 = v3(r6.w, r7.x, r7.y);
-  t.t0 = make_float2(r7.z, r7.w); t.t1 = make_float2(r8.x, r8.y); t.t2 = make_float2(r8.z, r8.w);
   QuadBary qb;
-  qb.projective = __float_as_int(r1.w) != 0;
-  if (qb.projective) {
-    const int X0 = __float_as_int(r0.x), Y0 = __float_as_int(r0.y), X1 = __float_as_int(r0.z), Y1 = __float_as_int(r0.w), X2 = __float_as_int(r1.x),
-              Y2 = __float_as_int(r1.y);
-    const long long px = (long long)qx * 256 + 128, py = (long long)qy * 256 + 128;
-    const int a0 = -(Y2 - Y1), b0 = X2 - X1, a1 = -(Y0 - Y2), b1 = X0 - X2;
-    const long long e0 = (long long)b0 * (py - Y1) + (long long)a0 * (px - X1);
-    const long long e1 = (long long)b1 * (py - Y2) + (long long)a1 * (px - X2);
-    const float inv_area = r1.z;
-    qb.l0 = (float)e0 * inv_area; qb.l1 = (float)e1 * inv_area;
-    qb.l0x = (float)(a0 * 256) * inv_area; qb.l0y = (float)(b0 * 256) * inv_area;
-    qb.l1x = (float)(a1 * 256) * inv_area; qb.l1y = (float)(b1 * 256) * inv_area;
-    qb.iw0 = r2.x; qb.iw1 = r2.y; qb.iw2 = r2.z;
-  } else {
-    // a vertex behind the eye or beyond the guard band (rare): the homogeneous form needs the clip positions
-    t.c0 = rec[9]; t.c1 = rec[10]; t.c2 = rec[11];
-  }
+  load_triangle(in, tri_id, qx, qy, t, qb);
   Varyings f, h0, h1, h2;
   if constexpr (UNIFORM) {
     f = varyings_at(t, qb, qx, qy, sub & 1, sub >> 1, p->W, p->H);
@@ -859,6 +807,51 @@ __global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(c
   }
 }
 
+// The same work lists for every other sampler: the general per-lane shading (address modes, nearest / linear
+// filters and mipmap use decided per lookup, transformed vertices read from memory) on the listed quads,
+// so background pixels start no wavefront here either and the visibility buffer is not read.
+constexpr int kGeneralThreads = 768;
+__global__ void __launch_bounds__(kGeneralThreads) resolve_surface_lists_kernel(const FrameParams frame_params, ResolveInputs in,
+                                                                                const float* __restrict__ srgb_lut, uint32_t* __restrict__ rgba8,
+                                                                                QuadLists lists, const uint32_t* __restrict__ counters) {
+  const FrameParams* __restrict__ p = &frame_params;
+  __shared__ float s_srgb[256];
+  __shared__ uint32_t s_next;
+  if (threadIdx.x < 256) s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
+  if (threadIdx.x == 0) s_next = 0u;
+  __syncthreads();
+  const uint32_t n_uniform = counters[6], n_mixed = counters[7];
+  const uint32_t items_mixed = (n_mixed + 15u) >> 4, items_uniform = (n_uniform + 15u) >> 4;
+  const uint32_t per_xcd = gridDim.x / kXcds, v = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds, nv = gridDim.x;
+  const uint32_t m_begin = (uint32_t)((unsigned long long)items_mixed * v / nv), m_end = (uint32_t)((unsigned long long)items_mixed * (v + 1) / nv);
+  const uint32_t u_begin = (uint32_t)((unsigned long long)items_uniform * v / nv), u_end = (uint32_t)((unsigned long long)items_uniform * (v + 1) / nv);
+  const uint32_t own_mixed = m_end - m_begin, own = own_mixed + (u_end - u_begin);
+  const int lane = threadIdx.x & 63, sub = lane & 3;
+  for (;;) {
+    uint32_t k = 0;
+    if (lane == 0) k = atomicAdd(&s_next, 1u);
+    k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
+    if (k >= own) break;
+    uint32_t pos, id;
+    bool live;
+    if (k >= own_mixed) {
+      const uint32_t q = (u_begin + k - own_mixed) * 16u + (uint32_t)(lane >> 2);
+      live = q < n_uniform;
+      const uint2 e = lists.uniform[live ? q : 0u];
+      pos = e.x; id = e.y;
+    } else {
+      const uint32_t q = (m_begin + k) * 16u + (uint32_t)(lane >> 2);
+      live = q < n_mixed;
+      pos = lists.mixed_pos[live ? q : 0u];
+      id = reinterpret_cast<const uint32_t*>(lists.mixed_ids)[(live ? q : 0u) * 4u + (uint32_t)sub];
+    }
+    if (!live) id = 0u;
+    const int qx = (int)(pos & 0xffffu) * 2, qy = p->y0 + (int)(pos >> 16) * 2;
+    const uint32_t color = shade_quad_lane<false, false>(p, in, s_srgb, id, qx, qy, lane, sub);
+    if (id != 0u) rgba8[(size_t)(qy + (sub >> 1) - p->y0) * p->W + qx + (sub & 1)] = color;
+  }
+}
+
 // Builds one level of a bordered cube (see cube_foot): [6][n + 2][n + 2] from [6][n][n].
 __global__ void __launch_bounds__(256) cube_border_kernel(DevCube src, int level, float4* __restrict__ dst) {
   const int n = max(1, src.size >> level), m = n + 2;
@@ -898,6 +891,12 @@ __global__ void __launch_bounds__(256) count_covered_kernel(const uint32_t* __re
 
 }  // namespace
 
+static int general_blocks_per_cu() {
+  static int blocks = 0;
+  if (blocks == 0 && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, resolve_surface_lists_kernel, kGeneralThreads, 0) != hipSuccess || blocks < 1)) blocks = 1;
+  return blocks;
+}
+
 int surface_fast_blocks_per_cu() {
   int blocks = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, resolve_surface_fast_kernel, kSurfaceThreads, 0) != hipSuccess || blocks < 1) blocks = 1;
@@ -912,8 +911,9 @@ void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in
     const int blocks = std::max(kXcds, resident_blocks / kXcds * kXcds);
     hipLaunchKernelGGL(resolve_surface_fast_kernel, dim3(blocks), dim3(kSurfaceThreads), 0, s, p, in, srgb_lut, out, lists, counters);
   } else {
-    dim3 grid((W + 31) / 32, (rows + 7) / 8);
-    hipLaunchKernelGGL(resolve_surface_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis, out);
+    const int per_cu = std::max(1, general_blocks_per_cu());
+    const int blocks = std::max(kXcds, (resident_blocks / std::max(1, surface_fast_blocks_per_cu())) * per_cu / kXcds * kXcds);
+    hipLaunchKernelGGL(resolve_surface_lists_kernel, dim3(blocks), dim3(kGeneralThreads), 0, s, p, in, srgb_lut, out, lists, counters);
   }
 }
 
