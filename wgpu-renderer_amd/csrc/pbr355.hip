@@ -140,15 +140,8 @@ int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out,
 }
 
 int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int samples) {
-  const size_t nv = (size_t)c->n_verts * c->n_instances;
   const size_t ntri = (size_t)(c->n_indices / 3) * c->n_instances;
   bool grew = false;
-  if (nv > c->vout_cap) {
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_dev(c->d_vout);
-    HIP_TRY(c, hipMalloc(&c->d_vout, nv * sizeof(VertexOut)));
-    c->vout_cap = nv; grew = true;
-  }
   if (ntri > c->record_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_dev(c->d_records);
@@ -795,9 +788,15 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   if (!c || !u) return PBR_E_ARG;
   if (!c->d_vsoa) return fail(c, PBR_E_STATE, "no mesh uploaded");
   DeviceGuard guard(c->device);
-  int rc = ensure_frame_buffers(c, 32, 32, 1, 1);
-  if (rc) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  {   // transformed vertices exist in memory only for this call: frames transform inside the setup kernel
+    const size_t want = (size_t)c->n_verts * c->n_instances;
+    if (want > c->vout_cap) {
+      free_dev(c->d_vout);
+      HIP_TRY(c, hipMalloc(&c->d_vout, want * sizeof(VertexOut)));
+      c->vout_cap = want;
+    }
+  }
   FrameParams fp;
   fp.u = *u;
   mat4_mul_host(u->projection, u->view, fp.pv);
