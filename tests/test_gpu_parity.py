@@ -335,6 +335,34 @@ def test_instanced_grid_matches_oracle():
         s.renderer.close()
 
 
+def test_stress_scene_strips_at_full_size():
+    """BASELINE config 5 at full size: 10 x 10 instanced helmets (1.5 M triangles), 7680 x 4320, eight 540-row strips
+    (the screen-strip split over eight GPUs, here one after the other on one): the strips put together are the
+    full frame, and a band through the middle row of helmets is the oracle's."""
+    pkg = pu._pkg()
+    from wgpu_renderer_amd import sharding
+    g = pkg.glTFLoader(); g.load(pkg.renderer.DEFAULT_MODEL)
+    base = np.asarray(g.get_geometries()[0].model, dtype=np.float32)
+    models = np.stack([pkg.mathx.mul(pkg.mathx.translate(pkg.mathx.identity(), [(i - 4.5) * 2.5, (j - 4.5) * 2.5, 0.0]), base) for j in range(10) for i in range(10)])
+    s = pu.SmallScene.build(width=7680, height=4320, instance_models=models)
+    try:
+        s.renderer.camera.update_camera_distance((5.0 - 30.0) * 100.0, 0.0)
+        rgba, vis, st = s.renderer.draw_frame(want_vis=True, want_stats=True)
+        assert st.covered_pixels == int((vis > 0).sum()) and st.covered_pixels > 5_000_000
+        assert len(np.unique((vis[vis > 0] - 1) // 15452)) == 100                    # every instance is on screen
+        for k in range(8):
+            y0, y1 = sharding.strip_rows(4320, k, 8)
+            assert (y0, y1) == (540 * k, 540 * (k + 1))
+            srgba, svis = s.render_gpu(y0, y1)
+            assert (srgba == rgba[y0:y1]).all() and (svis == vis[y0:y1]).all(), k
+        y0, y1 = 2360, 2392                                                           # through the helmets of the row below the centre
+        orgba, ovis = s.render_oracle(y0, y1)
+        assert (ovis > 0).mean() > 0.1 and (vis[y0:y1] == ovis).all()
+        assert_frame_close(rgba[y0:y1], orgba, vis[y0:y1], ovis, "8K band of the stress scene")
+    finally:
+        s.renderer.close()
+
+
 def test_prefilter_shards_compose(small):
     lib, r = small.pkg._lib, small.renderer
     whole = [r.download_map(lib.MAP_PREFILTER, l) for l in range(5)]
