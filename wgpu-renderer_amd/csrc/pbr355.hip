@@ -201,8 +201,9 @@ struct PbrContextPrivate {
   uint32_t frames_drawn = 0;
   // Bordered copies of the cube maps for the resolve: every face carries the adjoining texels of its
   // neighbours (and the three-texel mean at corners), so a bilinear lookup never leaves its face.
-  struct Bordered { float4* d = nullptr; DevCube cube = {}; bool dirty = true; };
+  struct Bordered { float* d = nullptr; DevCubeRgb cube = {}; bool dirty = true; };
   Bordered sky_b, irr_b, pre_b;
+  uint32_t* d_lut_pair = nullptr; int lut_pair_size = 0; bool lut_pair_dirty = true;   // two-channel copy of the BRDF table for the resolve
   int surface_blocks = 0;                 // resident workgroups of the surface kernel on this device
   int counter_set = 0;                    // which of the two sets of append counters the next frame uses
 };
@@ -238,10 +239,10 @@ static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const
       total += 6 * (n + 2) * (n + 2);
     }
     if (total > 0xffffffffull) return fail(c, PBR_E_ARG, "cube map too large");
-    HIP_TRY(c, hipMalloc(&b.d, total * sizeof(float4)));
+    HIP_TRY(c, hipMalloc(&b.d, total * 3 * sizeof(float)));
     b.cube.base = b.d; b.cube.size = src.size; b.cube.levels = src.levels;
   }
-  for (int l = 0; l < src.levels; ++l) launch_cube_border(c->stream, src, l, b.d + b.cube.off[l]);
+  for (int l = 0; l < src.levels; ++l) launch_cube_border(c->stream, src, l, b.d + 3 * (size_t)b.cube.off[l]);
   b.dirty = false;
   return PBR_OK;
 }
@@ -282,6 +283,16 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   hipStream_t s = c->stream;
 
   if ((rc = refresh_bordered(c, pr->sky_b, c->sky)) || (rc = refresh_bordered(c, pr->irr_b, c->irr)) || (rc = refresh_bordered(c, pr->pre_b, c->pre))) return rc;
+  if (pr->lut_pair_dirty || pr->lut_pair_size != c->lut_size) {
+    if (pr->lut_pair_size != c->lut_size) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (pr->d_lut_pair) { (void)hipFree(pr->d_lut_pair); pr->d_lut_pair = nullptr; }
+      HIP_TRY(c, hipMalloc(&pr->d_lut_pair, (size_t)c->lut_size * c->lut_size * sizeof(uint32_t)));
+      pr->lut_pair_size = c->lut_size;
+    }
+    launch_lut_pair(s, c->d_lut, pr->d_lut_pair, c->lut_size);
+    pr->lut_pair_dirty = false;
+  }
 
   const bool timed = stats != nullptr;
   const bool prof = c->profiling && c->prof_frames < c->prof_cap;
@@ -340,7 +351,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   for (int i = 0; i < 5; ++i) in.tex[i] = c->tex[i];
   in.irr = c->irr; in.pre = c->pre; in.sky = c->sky;
   in.irr_b = pr->irr_b.cube; in.pre_b = pr->pre_b.cube; in.sky_b = pr->sky_b.cube;
-  in.lut = c->d_lut; in.lut_size = c->lut_size;
+  in.lut = c->d_lut; in.lut_pair = pr->d_lut_pair; in.lut_size = c->lut_size;
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
   if (msaa) launch_surface_msaa(s, dp, in, pr->d_srgb_lut, vis, c->d_tile_live, color, W, rows, fast);
   else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->quad_lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
@@ -426,7 +437,7 @@ int pbr_destroy(PbrContext* c) {
   free_dev(c->d_vsoa); free_dev(c->d_indices); free_dev(c->d_inst_model); free_dev(c->d_inst_normal);
   for (auto& t : c->d_tex) free_dev(t);
   free_dev(c->d_hdr); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
-  { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); }
+  { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); free_dev(pr->d_lut_pair); }
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
   free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
   free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
@@ -677,6 +688,7 @@ int pbr_ibl_brdf_lut(PbrContext* c, int32_t size) {
     c->lut_size = size;
   }
   launch_brdf_lut(c->stream, c->d_lut, size);
+  priv_of(c)->lut_pair_dirty = true;
   HIP_TRY(c, hipGetLastError());
   return PBR_OK;
 }
@@ -750,6 +762,7 @@ int pbr_ibl_device_ptr(PbrContext* c, int which, void** dev_ptr, size_t* total_b
   PbrContextPrivate* pr = priv_of(c);
   if (which == PBR_MAP_SKYBOX) pr->sky_b.dirty = true;
   if (which == PBR_MAP_IRRADIANCE) pr->irr_b.dirty = true;
+  if (which == PBR_MAP_BRDF_LUT) pr->lut_pair_dirty = true;
   if (which == PBR_MAP_PREFILTER) pr->pre_b.dirty = true;
   *dev_ptr = p;
   if (total_bytes) *total_bytes = bytes;

@@ -36,6 +36,16 @@ struct DevCube {
   int32_t size, levels;
 };
 
+// The copy of a cube map the frame kernels sample: a one-texel border per face (the adjoining texels of the
+// neighbouring faces), and only the three channels the shaders read, as three floats per texel: a tap is one
+// 12-byte load, a quarter fewer bytes and registers than the rgba32f texel.
+struct DevCubeRgb {
+  const float* base;              // three floats per texel
+  uint32_t off[PBR_MAX_LEVELS];   // texel offset of each level
+  int32_t size, levels;           // size of level 0 without the border
+};
+
+
 // An equirectangular rgba32f image with its mip chain.
 struct DevEquirect {
   const float4* base;
@@ -167,15 +177,16 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSourc
                           int n_tris, int n_instances, const SkyShare& share);
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                    uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, const QuadLists& lists, bool write_vis,
-                   const DevCube& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y);
+                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y);
 struct ResolveInputs {
   const TriRecord* records;
   const VertexOut* vout;
   const uint32_t* indices;
   DevTex8 tex[5];
   DevCube irr, pre, sky;
-  DevCube irr_b, pre_b, sky_b;   // the same maps with a one-texel border per face (level l: [6][n+2][n+2], n = size >> l)
+  DevCubeRgb irr_b, pre_b, sky_b;   // the same maps with a one-texel border per face (level l: [6][n+2][n+2], n = size >> l), rgb only
   const uint16_t* lut;
+  const uint32_t* lut_pair;      // the table's two used channels per texel, A | B << 16 (half bits): half the footprint of the rgba16f table
   int32_t lut_size;
 };
 // covered pixels; the rasteriser has already written the skybox colour of the background pixels
@@ -189,6 +200,7 @@ void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* set
 void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, const uint32_t* tile_live,
                          uint8_t* rgba8, int W, int rows, bool fast);
 int surface_fast_blocks_per_cu();
-void launch_cube_border(hipStream_t s, DevCube src, int level, float4* dst_level);
+void launch_cube_border(hipStream_t s, DevCube src, int level, float* dst_level);   // dst: [6][n+2][n+2][3]
+void launch_lut_pair(hipStream_t s, const uint16_t* lut_rgba16f, uint32_t* pair, int size);
 // pixels with at least one covered sample
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n_pixels, int samples, uint32_t* covered);

@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
                                                      uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
                                                      const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
                                                      float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters,
-                                                     QuadLists lists, int write_vis, DevCube sky, uint32_t* __restrict__ rgba8, int sky_from_tile) {
+                                                     QuadLists lists, int write_vis, DevCubeRgb sky, uint32_t* __restrict__ rgba8, int sky_from_tile) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
   __shared__ uint32_t s_pairs[4], s_base[2];
@@ -678,7 +678,7 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSourc
 
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                    uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, const QuadLists& lists, bool write_vis,
-                   const DevCube& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y) {
+                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y) {
   hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
                      next_counters, lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile);
 }

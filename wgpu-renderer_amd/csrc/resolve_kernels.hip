@@ -697,10 +697,10 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   if ((ls & (ls - 1)) == 0) { lx0 &= ls - 1; lx1 &= ls - 1; ly0 &= ls - 1; ly1 &= ls - 1; }
   else { lx0 = ((lx0 % ls) + ls) % ls; lx1 = ((lx1 % ls) + ls) % ls; ly0 = ((ly0 % ls) + ls) % ls; ly1 = ((ly1 % ls) + ls) % ls; }
   if (bad_lut) { lx0 = lx1 = ly0 = ly1 = 0; }
-  float4 ti[4], ta[4], tb[4];
+  Rgb ti[4], ta[4], tb[4];
   cube_load4(in.irr_b.base, fi, ti); cube_load4(in.pre_b.base, fa, ta); cube_load4(in.pre_b.base, fb, tb);
-  const ushort4* lt = reinterpret_cast<const ushort4*>(in.lut);
-  const ushort4 u00 = lt[(uint32_t)ly0 * ls + lx0], u10 = lt[(uint32_t)ly0 * ls + lx1], u01 = lt[(uint32_t)ly1 * ls + lx0], u11 = lt[(uint32_t)ly1 * ls + lx1];
+  const uint32_t* lt = in.lut_pair;
+  const uint32_t u00 = lt[(uint32_t)ly0 * ls + lx0], u10 = lt[(uint32_t)ly0 * ls + lx1], u01 = lt[(uint32_t)ly1 * ls + lx0], u11 = lt[(uint32_t)ly1 * ls + lx1];
 
   // the rest of fs_main (shader.wgsl:95, :108-159)
   const V3 albedo = decode_fast<true>(t_alb, fp, s_srgb);
@@ -745,10 +745,10 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   if (bad_r) pf = v3(nanv, nanv, nanv);
   const float w00 = (1.0f - la) * (1.0f - lb), w10 = la * (1.0f - lb), w01 = (1.0f - la) * lb, w11 = la * lb;
   // NaN texels (column 0 of the table) poison the result even at zero weight: 0 * NaN = NaN
-  float bx = ((__half2float(__ushort_as_half(u00.x)) * w00 + __half2float(__ushort_as_half(u10.x)) * w10) + __half2float(__ushort_as_half(u01.x)) * w01) +
-             __half2float(__ushort_as_half(u11.x)) * w11;
-  float by = ((__half2float(__ushort_as_half(u00.y)) * w00 + __half2float(__ushort_as_half(u10.y)) * w10) + __half2float(__ushort_as_half(u01.y)) * w01) +
-             __half2float(__ushort_as_half(u11.y)) * w11;
+  auto lo = [](uint32_t v) { return __half2float(__ushort_as_half((unsigned short)(v & 0xffffu))); };
+  auto hi = [](uint32_t v) { return __half2float(__ushort_as_half((unsigned short)(v >> 16))); };
+  float bx = ((lo(u00) * w00 + lo(u10) * w10) + lo(u01) * w01) + lo(u11) * w11;
+  float by = ((hi(u00) * w00 + hi(u10) * w10) + hi(u01) * w01) + hi(u11) * w11;
   if (bad_lut) { bx = nanv; by = nanv; }
   const V3 specular = v3(pf.x * (kS.x * bx + by), pf.y * (kS.y * bx + by), pf.z * (kS.z * bx + by));
   const V3 ambient = v3((kD.x * irr.x * albedo.x + specular.x) * occlusion, (kD.y * irr.y * albedo.y + specular.y) * occlusion,
@@ -853,7 +853,7 @@ __global__ void __launch_bounds__(kGeneralThreads) resolve_surface_lists_kernel(
 }
 
 // Builds one level of a bordered cube (see cube_foot): [6][n + 2][n + 2] from [6][n][n].
-__global__ void __launch_bounds__(256) cube_border_kernel(DevCube src, int level, float4* __restrict__ dst) {
+__global__ void __launch_bounds__(256) cube_border_kernel(DevCube src, int level, float* __restrict__ dst) {
   const int n = max(1, src.size >> level), m = n + 2;
   const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
   if (idx >= 6u * m * m) return;
@@ -869,7 +869,13 @@ __global__ void __launch_bounds__(256) cube_border_kernel(DevCube src, int level
     out = make_float4(((a.x + b.x) + c.x) * (1.0f / 3.0f), ((a.y + b.y) + c.y) * (1.0f / 3.0f), ((a.z + b.z) + c.z) * (1.0f / 3.0f),
                       ((a.w + b.w) + c.w) * (1.0f / 3.0f));
   }
-  dst[idx] = out;
+  dst[3 * (size_t)idx] = out.x; dst[3 * (size_t)idx + 1] = out.y; dst[3 * (size_t)idx + 2] = out.z;
+}
+
+// The two channels fs_main reads from the rgba16f BRDF table (shader.wgsl:150-151), packed for the resolve.
+__global__ void __launch_bounds__(256) lut_pair_kernel(const uint16_t* __restrict__ lut, uint32_t* __restrict__ pair, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const ushort4 t = reinterpret_cast<const ushort4*>(lut)[i]; pair[i] = (uint32_t)t.x | ((uint32_t)t.y << 16); }
 }
 
 // Number of covered pixels, for the frame statistics only: one atomic per 16384 pixels (a single
@@ -927,7 +933,11 @@ void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInput
   else hipLaunchKernelGGL(resolve_surface_msaa_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis4, tile_live, out);
 }
 
-void launch_cube_border(hipStream_t s, DevCube src, int level, float4* dst_level) {
+void launch_lut_pair(hipStream_t s, const uint16_t* lut_rgba16f, uint32_t* pair, int size) {
+  hipLaunchKernelGGL(lut_pair_kernel, dim3((unsigned)(((size_t)size * size + 255) / 256)), dim3(256), 0, s, lut_rgba16f, pair, size * size);
+}
+
+void launch_cube_border(hipStream_t s, DevCube src, int level, float* dst_level) {
   const int n = std::max(1, src.size >> level), m = n + 2;
   hipLaunchKernelGGL(cube_border_kernel, dim3((unsigned)((6u * m * m + 255u) / 256u)), dim3(256), 0, s, src, level, dst_level);
 }

@@ -33,7 +33,7 @@ struct CubeFoot { uint32_t o; uint32_t m; float w[4]; };   // taps at o, o + 1, 
 // cube: the border row / column of a face holds the adjoining texels of the neighbouring faces and a
 // border corner the mean of the three texels around it, which is what a lookup across an edge or a
 // corner blends, so the four taps always sit in one face.
-PBR_DEV CubeFoot cube_foot(const DevCube& bordered, int level, const CubeCoord& c) {
+PBR_DEV CubeFoot cube_foot(const DevCubeRgb& bordered, int level, const CubeCoord& c) {
 #pragma clang fp contract(fast)
   CubeFoot f;
   const int n = max(1, bordered.size >> level), m = n + 2;
@@ -47,13 +47,14 @@ PBR_DEV CubeFoot cube_foot(const DevCube& bordered, int level, const CubeCoord& 
   f.m = (uint32_t)m;
   return f;
 }
-PBR_DEV void cube_load4(const float4* base, const CubeFoot& f, float4 t[4]) {
-  const float4* q = base + f.o;
+struct Rgb { float x, y, z; };   // one texel of a DevCubeRgb: 12 bytes, fetched with one three-dword load
+PBR_DEV void cube_load4(const float* base, const CubeFoot& f, Rgb t[4]) {
+  const Rgb* q = reinterpret_cast<const Rgb*>(base) + f.o;
   t[0] = q[0]; t[1] = q[1]; t[2] = q[f.m]; t[3] = q[f.m + 1];
 }
 
 
-PBR_DEV V3 weigh4(const float4 t[4], const float w[4]) {
+PBR_DEV V3 weigh4(const Rgb t[4], const float w[4]) {
 #pragma clang fp contract(fast)
   return v3(((t[0].x * w[0] + t[1].x * w[1]) + t[2].x * w[2]) + t[3].x * w[3], ((t[0].y * w[0] + t[1].y * w[1]) + t[2].y * w[2]) + t[3].y * w[3],
             ((t[0].z * w[0] + t[1].z * w[1]) + t[2].z * w[2]) + t[3].z * w[3]);
@@ -78,7 +79,7 @@ PBR_DEV void cube_face_coords(int face, V3 d, float& sc, float& tc, float& rc) {
 // cube face is selected once, for the first pixel, and the face coordinates of the other three are
 // that pixel's plus a constant step; a pixel that has left the face (its major axis is no longer
 // the largest component, or w has changed sign) takes the full selection again.
-PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCube& sky, int x0, int y, uint32_t out[4]) {
+PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sky, int x0, int y, uint32_t out[4]) {
 #pragma clang fp contract(fast)
   const float* m = p->u.inv_view_proj;
   const float two_over_w = 2.0f / (float)p->W;
@@ -111,7 +112,7 @@ PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCube& sky, 
     }
     foot[k] = cube_foot(sky, 0, c);
   }
-  float4 tap[4][4];
+  Rgb tap[4][4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) cube_load4(sky.base, foot[k], tap[k]);
 #pragma unroll
@@ -122,14 +123,14 @@ PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCube& sky, 
 // any 256-thread workgroup: the geometry kernels of a frame are short and latency-bound, so a share
 // of the tiles rides along in their launches as extra workgroups and fills the otherwise idle chip.
 struct SkyShare {
-  DevCube sky;        // bordered skybox cube
+  DevCubeRgb sky;     // bordered skybox cube
   uint32_t* rgba8;    // colour target of the row range
   int first, count;   // tiles [first, first + count) are shaded by the workgroups after the kernel's own
   int own_blocks;     // number of workgroups that do the kernel's own work
 };
 
 // Every pixel of tile `tile` gets the skybox colour (covered ones are overwritten by the surface pass).
-PBR_DEV void sky_tile(const FrameParams* __restrict__ p, const DevCube& sky, uint32_t* __restrict__ rgba8, int tile) {
+PBR_DEV void sky_tile(const FrameParams* __restrict__ p, const DevCubeRgb& sky, uint32_t* __restrict__ rgba8, int tile) {
   const int tile_x = tile % p->tiles_x, tile_y = tile / p->tiles_x;
   const int x = tile_x * PBR_TILE + (threadIdx.x & 7) * 4, y = p->y0 + tile_y * PBR_TILE + (threadIdx.x >> 3);
   if (x >= p->W || y >= p->y1) return;
