@@ -1,4 +1,4 @@
-"""Runs the IBL prefilter at BASELINE config 3 (2048^2, 10 mips, 1024 samples) a few times, for profilers."""
+"""Runs the IBL prefilter at the large benchmark size (2048^2, 10 mips, 1024 samples) a few times, for profilers."""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,4 @@
-"""BASELINE config 5 on one GPU: 10x10 instanced DamagedHelmet (spacing 2.5, camera distance 30) at
+"""The 8K stress configuration on one GPU: 10x10 instanced DamagedHelmet (spacing 2.5, camera distance 30) at
 7680x4320, whole frame and one of eight 540-row strips."""
 import os, sys, time
 import numpy as np

@@ -264,7 +264,7 @@ def test_strips_equal_full_frame(small):
 
 
 def test_reference_sizes_720p(refsize):
-    """BASELINE config 1: 1280x720 single frame with the reference's IBL sizes."""
+    """The 1280x720 single frame with the reference's IBL sizes."""
     lib, r, m = refsize.pkg._lib, refsize.renderer, refsize.oracle.maps()
     assert_map_close(r.download_map(lib.MAP_IRRADIANCE), m["irr"], "irradiance 32", share=2e-3)
     for lvl in range(5):
@@ -284,7 +284,7 @@ def test_reference_sizes_720p(refsize):
 
 
 def test_4k_frame_properties(refsize):
-    """BASELINE config 2 at full size: a band through the helmet against the oracle, strips against
+    """The 3840x2160 benchmark frame at full size: a band through the helmet against the oracle, strips against
     the full frame, run-to-run determinism, and the coverage counter against the visibility buffer."""
     r = refsize.renderer
     r.width, r.height = 3840, 2160
@@ -336,7 +336,7 @@ def test_instanced_grid_matches_oracle():
 
 
 def test_stress_scene_strips_at_full_size():
-    """BASELINE config 5 at full size: 10 x 10 instanced helmets (1.5 M triangles), 7680 x 4320, eight 540-row strips
+    """The synthetic stress scene at full size: 10 x 10 instanced helmets (1.5 M triangles), 7680 x 4320, eight 540-row strips
     (the screen-strip split over eight GPUs, here one after the other on one): the strips put together are the
     full frame, and a band through the middle row of helmets is the oracle's."""
     pkg = pu._pkg()
@@ -387,7 +387,7 @@ def test_prefilter_shards_compose(small):
 
 
 def test_large_prefilter_spot_checks():
-    """BASELINE config 3 (2048^2 cube, 10 mips, 1024 samples): full-size GPU run, oracle on sampled texel ranges."""
+    """The large prefilter configuration (2048^2 cube, 10 mips, 1024 samples): full-size GPU run, oracle on sampled texel ranges."""
     pkg = pu._pkg()
     lib = pkg._lib
     hdr = pkg.synthetic_sky(4096, 2048)
