@@ -44,8 +44,8 @@ def measured_traffic(kernel):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=360, help="frames per rank in the timed region (360 = one full orbit on one GPU)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--skybox-size", type=int, default=1024)
