@@ -21,9 +21,14 @@ PBR_DEV CubeCoord cube_select(V3 r) {
 PBR_DEV uint32_t pack_color(V3 color) {
 #pragma clang fp contract(fast)
   // pow(c, 1/2.2) as exp2(log2(c) / 2.2) (shader.wgsl:157, skybox.wgsl:30): 0 -> 0, negative or NaN -> NaN -> 0
+  // unorm8 conversion: v_cvt_pk_u8_f32 rounds to nearest even, saturates to [0, 255], turns NaN into 0 and drops
+  // the byte into place, which is the whole of "clamp, scale, round, pack" in one instruction per channel
   const float g = 1.0f / 2.2f;
-  return to_unorm8(exp2_fast(log2_fast(color.x) * g)) | (to_unorm8(exp2_fast(log2_fast(color.y) * g)) << 8) |
-         (to_unorm8(exp2_fast(log2_fast(color.z) * g)) << 16) | 0xff000000u;
+  uint32_t packed = 0xff000000u;
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(exp2_fast(log2_fast(color.x) * g) * 255.0f, 0u, packed);
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(exp2_fast(log2_fast(color.y) * g) * 255.0f, 1u, packed);
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(exp2_fast(log2_fast(color.z) * g) * 255.0f, 2u, packed);
+  return packed;
 }
 
 
@@ -77,8 +82,8 @@ PBR_DEV void cube_face_coords(int face, V3 d, float& sc, float& tc, float& rc) {
 // unprojected with the inverse view-projection matrix and the bordered cube sampled bilinearly; all
 // sixteen taps are issued before any is used.  The unprojected direction is affine in x, so the
 // cube face is selected once, for the first pixel, and the face coordinates of the other three are
-// that pixel's plus a constant step; a pixel that has left the face (its major axis is no longer
-// the largest component, or w has changed sign) takes the full selection again.
+// that pixel's plus a constant step; when the group straddles a face edge (or w changes sign in
+// it) the other three take the full selection again.
 PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sky, int x0, int y, uint32_t out[4]) {
 #pragma clang fp contract(fast)
   const float* m = p->u.inv_view_proj;
@@ -98,14 +103,18 @@ PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sk
   cube_face_coords(first.face, step, dsc, dtc, drc);
   CubeFoot foot[4];
   foot[0] = cube_foot(sky, 0, first);
+  // A face is a convex cone of directions and the four directions lie on a segment, so all four pixels are on
+  // the first pixel's face (with w of one sign) exactly when the last one is: one test instead of three.
+  const float w3 = tw + 3.0f * w_step;
+  const float sc3 = first.sc + 3.0f * dsc, tc3 = first.tc + 3.0f * dtc, rc3 = first.rc + 3.0f * drc;
+  const bool one_face = fabsf(rc3) >= fabsf(sc3) && fabsf(rc3) >= fabsf(tc3) && (rc3 < 0.0f) == (first.rc < 0.0f) && (w3 < 0.0f) == (tw < 0.0f);
 #pragma unroll
   for (int k = 1; k < 4; ++k) {
     CubeCoord c;
     c.face = first.face;
     c.sc = first.sc + (float)k * dsc; c.tc = first.tc + (float)k * dtc; c.rc = first.rc + (float)k * drc;
-    const float wk = tw + (float)k * w_step;
-    const bool same_face = fabsf(c.rc) >= fabsf(c.sc) && fabsf(c.rc) >= fabsf(c.tc) && (c.rc < 0.0f) == (first.rc < 0.0f) && (wk < 0.0f) == (tw < 0.0f);
-    if (!same_face) {
+    if (!one_face) {
+      const float wk = tw + (float)k * w_step;
       const float sk = wk < 0.0f ? -1.0f : 1.0f, xk = xn + (float)k * two_over_w;
       const float ax = ((m[0] * xk + m[4] * yn) + m[8]) + m[12], ay = ((m[1] * xk + m[5] * yn) + m[9]) + m[13], az = ((m[2] * xk + m[6] * yn) + m[10]) + m[14];
       c = cube_select(v3(ax * sk, ay * sk, -(az * sk)));
