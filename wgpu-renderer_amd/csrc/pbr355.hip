@@ -279,6 +279,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances;
   fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
   fp.msaa = msaa ? 1 : 0;
+  fp.two_over_w = 2.0f / (float)W; fp.two_over_h = 2.0f / (float)H;
   const FrameParams& dp = fp;
   hipStream_t s = c->stream;
 
@@ -816,6 +817,7 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   fp.W = 32; fp.H = 32; fp.y0 = 0; fp.y1 = 32; fp.tiles_x = 1; fp.tiles_y = 1;
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances; fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
   fp.msaa = 0;
+  fp.two_over_w = 2.0f / 32.0f; fp.two_over_h = 2.0f / 32.0f;
   SkyShare none = {};
   launch_vertex_stage(c->stream, fp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances, none);
   HIP_TRY(c, hipStreamSynchronize(c->stream));

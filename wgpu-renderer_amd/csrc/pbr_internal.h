@@ -104,6 +104,7 @@ struct FrameParams {
   int32_t n_verts, n_tris, n_instances;
   int32_t has_instance_mats;
   int32_t msaa;             // 1 = four samples per pixel (bit 16 of the sampler index, renderer.ts:1927-1932)
+  float two_over_w, two_over_h;   // 2 / W, 2 / H (one correctly rounded division each, done once on the host)
 };
 
 struct PbrContext {

@@ -10,11 +10,18 @@ struct CubeCoord { int face; float sc, tc, rc; };
 
 PBR_DEV CubeCoord cube_select(V3 r) {
 #pragma clang fp contract(fast)
+  // selects only, no branches: lanes of one wavefront usually look at different faces
   const float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
+  const bool use_z = az >= ax && az >= ay, use_y = !use_z && ay >= ax;
+  const float rc = use_z ? r.z : use_y ? r.y : r.x;
+  const bool pos = rc >= 0.0f;
   CubeCoord c;
-  if (az >= ax && az >= ay) { c.face = r.z >= 0 ? 4 : 5; c.sc = r.z >= 0 ? r.x : -r.x; c.tc = -r.y; c.rc = r.z; }
-  else if (ay >= ax)        { c.face = r.y >= 0 ? 2 : 3; c.sc = r.x; c.tc = r.y >= 0 ? r.z : -r.z; c.rc = r.y; }
-  else                      { c.face = r.x >= 0 ? 0 : 1; c.sc = r.x >= 0 ? -r.z : r.z; c.tc = -r.y; c.rc = r.x; }
+  c.rc = rc;
+  c.face = (use_z ? 4 : use_y ? 2 : 0) + (pos ? 0 : 1);
+  const float sx = use_z || use_y ? r.x : -r.z;          // sc before the sign of the major axis is applied
+  c.sc = (use_y || pos) ? sx : -sx;
+  const float tz = pos ? r.z : -r.z;
+  c.tc = use_y ? tz : -r.y;
   return c;
 }
 
@@ -68,14 +75,11 @@ PBR_DEV V3 weigh4(const Rgb t[4], const float w[4]) {
 
 // Face coordinates (sc, tc, rc) of direction d on a given face: the rows of the face-selection table.
 PBR_DEV void cube_face_coords(int face, V3 d, float& sc, float& tc, float& rc) {
-  switch (face) {
-    case 0: sc = -d.z; tc = -d.y; rc = d.x; break;
-    case 1: sc = d.z;  tc = -d.y; rc = d.x; break;
-    case 2: sc = d.x;  tc = d.z;  rc = d.y; break;
-    case 3: sc = d.x;  tc = -d.z; rc = d.y; break;
-    case 4: sc = d.x;  tc = -d.y; rc = d.z; break;
-    default: sc = -d.x; tc = -d.y; rc = d.z; break;
-  }
+  const bool fx = face < 2, fy = (face & 6) == 2, odd = (face & 1) != 0;
+  rc = fx ? d.x : fy ? d.y : d.z;
+  const float s0 = fx ? -d.z : d.x;                       // faces 0, 2, 3, 4; negated on faces 1 and 5
+  sc = (odd && !fy) ? -s0 : s0;
+  tc = fy ? (odd ? -d.z : d.z) : -d.y;
 }
 
 // Skybox colour of four horizontally adjacent pixels (x0 .. x0+3, y): the clip-space position is
@@ -87,8 +91,8 @@ PBR_DEV void cube_face_coords(int face, V3 d, float& sc, float& tc, float& rc) {
 PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sky, int x0, int y, uint32_t out[4]) {
 #pragma clang fp contract(fast)
   const float* m = p->u.inv_view_proj;
-  const float two_over_w = 2.0f / (float)p->W;
-  const float yn = 1.0f - ((float)y + 0.5f) * (2.0f / (float)p->H);
+  const float two_over_w = p->two_over_w;
+  const float yn = 1.0f - ((float)y + 0.5f) * p->two_over_h;
   const float xn = ((float)x0 + 0.5f) * two_over_w - 1.0f;
   // normalize(xyz / w) only rescales the lookup direction by 1 / (w |xyz|); the cube lookup depends on
   // the direction alone, so only the sign of w is applied.
