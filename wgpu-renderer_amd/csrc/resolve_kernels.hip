@@ -109,16 +109,6 @@ PBR_DEV float2 sample_lut(const uint16_t* lut, int size, uint32_t sampler, float
 }
 
 // ---------------- cube maps ----------------
-PBR_DEV void cube_table(int face, V3 d, float& sc, float& tc, float& rc) {
-  switch (face) {
-    case 0: sc = -d.z; tc = -d.y; rc = d.x; break;
-    case 1: sc = d.z;  tc = -d.y; rc = d.x; break;
-    case 2: sc = d.x;  tc = d.z;  rc = d.y; break;
-    case 3: sc = d.x;  tc = -d.z; rc = d.y; break;
-    case 4: sc = d.x;  tc = -d.y; rc = d.z; break;
-    default: sc = -d.x; tc = -d.y; rc = d.z; break;
-  }
-}
 PBR_DEV V3 cube_dir(int face, float sc, float tc) {
   switch (face) {
     case 0: return v3(1.0f, -tc, -sc);
@@ -185,7 +175,7 @@ PBR_DEV float cube_lambda(int size, V3 r, V3 drdx, V3 drdy) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     float dsc, dtc, drc;
-    cube_table(c.face, d[k], dsc, dtc, drc);
+    cube_face_coords(c.face, d[k], dsc, dtc, drc);
     const float dma = sgn * drc;
     const float ds = 0.5f * ((ma * dsc - c.sc * dma) * inv_rc2), dt = 0.5f * ((ma * dtc - c.tc * dma) * inv_rc2);
     const float mu = ds * (float)size, mv = dt * (float)size;
