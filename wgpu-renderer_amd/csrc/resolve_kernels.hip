@@ -751,12 +751,12 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
 // wavefront, four lanes per quad).  One workgroup per compute unit, as many wavefronts as the unit
 // holds.  The lists are in tile order, so a contiguous stretch of a list is a compact piece of the
 // screen and of the textures: workgroups are numbered XCD-major (hardware deals workgroup i to XCD
-// i mod 8) and each takes one contiguous stretch of either list, which keeps a unit's twelve waves
+// i mod 8) and each takes one contiguous stretch of either list, which keeps a unit's sixteen waves
 // on neighbouring quads (L1) and an XCD's units on one eighth of the frame (its private L2).  The
 // waves of a workgroup claim its items one at a time from a counter in LDS, mixed quads (the
 // costlier ones) first, so they finish within one item of each other.
 #ifndef PBR_SURFACE_THREADS
-#define PBR_SURFACE_THREADS 768
+#define PBR_SURFACE_THREADS 1024   // 128 VGPRs, four waves per SIMD (a handful of cold-path spills; measured ahead of 768 threads at 147 VGPRs)
 #endif
 constexpr int kSurfaceThreads = PBR_SURFACE_THREADS;
 constexpr int kXcds = 8;
