@@ -82,6 +82,56 @@ PBR_DEV void cube_face_coords(int face, V3 d, float& sc, float& tc, float& rc) {
   tc = fy ? (odd ? -d.z : d.z) : -d.y;
 }
 
+// Two-wide arithmetic: CDNA issues one vector instruction per SIMD every four cycles whether it carries
+// one f32 per lane or two (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32), so the skybox works on pairs of
+// pixels.  Each element goes through exactly the operations of the one-pixel functions above.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct CubeFootPair { uint32_t o[2]; uint32_t m; f2 w[4]; };   // element k of each weight belongs to the pixel with offset o[k]
+
+// cube_foot on level 0 for two lookups at once (faces and face coordinates given per element).
+PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int face1, f2 sc, f2 tc, f2 rc) {
+#pragma clang fp contract(fast)
+  CubeFootPair f;
+  const int n = max(1, bordered.size), m = n + 2;
+  const float fn = (float)n;
+  const f2 ima = {rcp_fast(fabsf(rc.x)), rcp_fast(fabsf(rc.y))};
+  const f2 s = 0.5f * (sc * ima) + 0.5f, t = 0.5f * (tc * ima) + 0.5f;
+  const f2 tu = s * fn - 0.5f, tv = t * fn - 0.5f;
+  const f2 fu = {floorf(tu.x), floorf(tu.y)}, fv = {floorf(tv.x), floorf(tv.y)};
+  const f2 a = tu - fu, b = tv - fv;
+  const f2 oma = 1.0f - a, omb = 1.0f - b;
+  f.w[0] = oma * omb; f.w[1] = a * omb; f.w[2] = oma * b; f.w[3] = a * b;
+  const int i0 = min(max((int)fu.x, -1), n - 1), j0 = min(max((int)fv.x, -1), n - 1);
+  const int i1 = min(max((int)fu.y, -1), n - 1), j1 = min(max((int)fv.y, -1), n - 1);
+  f.o[0] = bordered.off[0] + ((uint32_t)face0 * m + (uint32_t)(j0 + 1)) * m + (uint32_t)(i0 + 1);
+  f.o[1] = bordered.off[0] + ((uint32_t)face1 * m + (uint32_t)(j1 + 1)) * m + (uint32_t)(i1 + 1);
+  f.m = (uint32_t)m;
+  return f;
+}
+
+// weigh4 for pixel E of a pair: red and green as one two-wide chain, blue alone.
+template <int E>
+PBR_DEV V3 weigh4_of_pair(const Rgb t[4], const f2 w[4]) {
+#pragma clang fp contract(fast)
+  const f2 rg = (((f2){t[0].x, t[0].y} * w[0][E] + (f2){t[1].x, t[1].y} * w[1][E]) + (f2){t[2].x, t[2].y} * w[2][E]) + (f2){t[3].x, t[3].y} * w[3][E];
+  const float bl = ((t[0].z * w[0][E] + t[1].z * w[1][E]) + t[2].z * w[2][E]) + t[3].z * w[3][E];
+  return v3(rg.x, rg.y, bl);
+}
+
+// pack_color for two pixels: the two multiplies of each channel run two-wide.
+PBR_DEV void pack_color_pair(V3 c0, V3 c1, uint32_t& out0, uint32_t& out1) {
+#pragma clang fp contract(fast)
+  const float g = 1.0f / 2.2f;
+  const f2 lx = (f2){log2_fast(c0.x), log2_fast(c1.x)} * g, ly = (f2){log2_fast(c0.y), log2_fast(c1.y)} * g, lz = (f2){log2_fast(c0.z), log2_fast(c1.z)} * g;
+  const f2 ex = (f2){exp2_fast(lx.x), exp2_fast(lx.y)} * 255.0f, ey = (f2){exp2_fast(ly.x), exp2_fast(ly.y)} * 255.0f, ez = (f2){exp2_fast(lz.x), exp2_fast(lz.y)} * 255.0f;
+  uint32_t p0 = 0xff000000u, p1 = 0xff000000u;
+  p0 = __builtin_amdgcn_cvt_pk_u8_f32(ex.x, 0u, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(ex.y, 0u, p1);
+  p0 = __builtin_amdgcn_cvt_pk_u8_f32(ey.x, 1u, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(ey.y, 1u, p1);
+  p0 = __builtin_amdgcn_cvt_pk_u8_f32(ez.x, 2u, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(ez.y, 2u, p1);
+  out0 = p0; out1 = p1;
+}
+
 // Skybox colour of four horizontally adjacent pixels (x0 .. x0+3, y): the clip-space position is
 // unprojected with the inverse view-projection matrix and the bordered cube sampled bilinearly; all
 // sixteen taps are issued before any is used.  The unprojected direction is affine in x, so the
@@ -105,31 +155,43 @@ PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sk
   const CubeCoord first = cube_select(d0);
   float dsc, dtc, drc;
   cube_face_coords(first.face, step, dsc, dtc, drc);
-  CubeFoot foot[4];
-  foot[0] = cube_foot(sky, 0, first);
   // A face is a convex cone of directions and the four directions lie on a segment, so all four pixels are on
   // the first pixel's face (with w of one sign) exactly when the last one is: one test instead of three.
   const float w3 = tw + 3.0f * w_step;
-  const float sc3 = first.sc + 3.0f * dsc, tc3 = first.tc + 3.0f * dtc, rc3 = first.rc + 3.0f * drc;
-  const bool one_face = fabsf(rc3) >= fabsf(sc3) && fabsf(rc3) >= fabsf(tc3) && (rc3 < 0.0f) == (first.rc < 0.0f) && (w3 < 0.0f) == (tw < 0.0f);
+  const f2 k01 = {0.0f, 1.0f}, k23 = {2.0f, 3.0f};
+  f2 sc01 = first.sc + k01 * dsc, tc01 = first.tc + k01 * dtc, rc01 = first.rc + k01 * drc;
+  f2 sc23 = first.sc + k23 * dsc, tc23 = first.tc + k23 * dtc, rc23 = first.rc + k23 * drc;
+  sc01.x = first.sc; tc01.x = first.tc; rc01.x = first.rc;   // pixel 0 exactly as selected (0 * step may be NaN)
+  int face[4] = {first.face, first.face, first.face, first.face};
+  const bool one_face = fabsf(rc23.y) >= fabsf(sc23.y) && fabsf(rc23.y) >= fabsf(tc23.y) && (rc23.y < 0.0f) == (first.rc < 0.0f) && (w3 < 0.0f) == (tw < 0.0f);
+#ifdef SKY_NO_FALLBACK
+  if (false) {
+#else
+  if (!one_face) {
+#endif
+    CubeCoord c[4];
 #pragma unroll
-  for (int k = 1; k < 4; ++k) {
-    CubeCoord c;
-    c.face = first.face;
-    c.sc = first.sc + (float)k * dsc; c.tc = first.tc + (float)k * dtc; c.rc = first.rc + (float)k * drc;
-    if (!one_face) {
+    for (int k = 1; k < 4; ++k) {
       const float wk = tw + (float)k * w_step;
       const float sk = wk < 0.0f ? -1.0f : 1.0f, xk = xn + (float)k * two_over_w;
       const float ax = ((m[0] * xk + m[4] * yn) + m[8]) + m[12], ay = ((m[1] * xk + m[5] * yn) + m[9]) + m[13], az = ((m[2] * xk + m[6] * yn) + m[10]) + m[14];
-      c = cube_select(v3(ax * sk, ay * sk, -(az * sk)));
+      c[k] = cube_select(v3(ax * sk, ay * sk, -(az * sk)));
+      face[k] = c[k].face;
     }
-    foot[k] = cube_foot(sky, 0, c);
+    sc01.y = c[1].sc; tc01.y = c[1].tc; rc01.y = c[1].rc;
+    sc23 = (f2){c[2].sc, c[3].sc}; tc23 = (f2){c[2].tc, c[3].tc}; rc23 = (f2){c[2].rc, c[3].rc};
   }
+  const CubeFootPair fa = cube_foot_pair(sky, face[0], face[1], sc01, tc01, rc01), fb = cube_foot_pair(sky, face[2], face[3], sc23, tc23, rc23);
   Rgb tap[4][4];
+  const Rgb* base = reinterpret_cast<const Rgb*>(sky.base);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) cube_load4(sky.base, foot[k], tap[k]);
-#pragma unroll
-  for (int k = 0; k < 4; ++k) out[k] = pack_color(weigh4(tap[k], foot[k].w));
+  for (int k = 0; k < 4; ++k) {
+    const CubeFootPair& f = k < 2 ? fa : fb;
+    const Rgb* q = base + f.o[k & 1];
+    tap[k][0] = q[0]; tap[k][1] = q[1]; tap[k][2] = q[f.m]; tap[k][3] = q[f.m + 1];
+  }
+  pack_color_pair(weigh4_of_pair<0>(tap[0], fa.w), weigh4_of_pair<1>(tap[1], fa.w), out[0], out[1]);
+  pack_color_pair(weigh4_of_pair<0>(tap[2], fb.w), weigh4_of_pair<1>(tap[3], fb.w), out[2], out[3]);
 }
 
 // The skybox pass is cut into the same 32 x 32 pixel tiles as the rasteriser.  A tile can be shaded by
