@@ -5,12 +5,12 @@ A step is one 3840x2160 DamagedHelmet PBR+IBL frame (vertex transform, binning, 
 surface shading) rendered into device memory with every input already resident in HBM.  With
 --gpus N > 1 the frames of a camera orbit (one `updateCameraRotation(-10, 0)` step per frame) are
 dealt round-robin to the ranks, one process per GPU, no data-path collective: weak scaling.  Each
-rank keeps --in-flight frames in flight (default 2): that many renderer contexts, each on its own
+rank keeps --in-flight frames in flight (default 3): that many renderer contexts, each on its own
 stream with its own colour target, take the rank's frames in turn, so the short latency-bound
 geometry kernels of one frame overlap the shading of the previous one.
 
 Prints ONE JSON line on rank 0.  `roofline` is for the surface-shading kernel, timed with HIP events
-on the stream it runs on over the timed region (where it shares the chip with the other frame in
+on the stream it runs on over the timed region (where it shares the chip with the other frames in
 flight); `roofline.isolated` is the same kernel on the same frames with nothing else running.
 `cpu_baseline` is the CPU oracle (a restatement of the reference WGSL, not Dawn/SwiftShader)
 rendering frames of the same orbit on the host cores.
@@ -49,7 +49,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--skybox-size", type=int, default=1024)
-    ap.add_argument("--in-flight", type=int, default=2,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="frames in flight per GPU: that many renderer contexts, each on its own stream, take the rank's frames in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the IBL prefilter timing (2048^2, 10 mips)")

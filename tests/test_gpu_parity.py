@@ -28,13 +28,9 @@ def rel_err(got, ref):
 
 
 def assert_map_close(got, ref, name, share=1e-3, worst=0.5):
-    """Within 1e-3 relative but for a `share` of the values.  A tap whose equirect coordinate lies within
-    rounding distance of a pixel border may read the neighbouring pixel (the arctangent differs in the last
-    bit between implementations); beside the 5000-fold sun of the test sky one such tap moves its texel by
-    far more than 1e-3, so a handful of values may exceed `worst`, none by more than the sun allows."""
     e = rel_err(got[..., :3], ref[..., :3])
     assert (e > 1e-3).mean() <= share, f"{name}: {(e > 1e-3).mean():.5f} of texels beyond 1e-3 (max {e.max():.3e})"
-    assert (e >= worst).sum() <= max(3, int(1e-5 * e.size)) and e.max() < 10.0, f"{name}: {(e >= worst).sum()} values beyond {worst} (max {e.max():.3e})"
+    assert e.max() < worst, f"{name}: max relative error {e.max():.3e}"
     assert (got[..., 3] == 1.0).all(), name
 
 

@@ -143,6 +143,15 @@ __global__ void __launch_bounds__(256) irradiance_kernel(DevEquirect hdr, const 
   }
 }
 
+// Light direction of one tabulated sample in world space.  The equirect pixel a sample reads flips with the last
+// bit of this sum, so its rounding is spelled out (first two terms fused, the third product rounded on its own)
+// instead of being left to the compiler's choice of contractions.
+PBR_DEV V3 sample_to_world(const V3& T, const V3& B, const V3& N, float lx, float ly, float lz) {
+#pragma clang fp contract(off)
+  const float nx = N.x * lz, ny = N.y * lz, nz = N.z * lz;
+  return v3(fmaf(ly, B.x, T.x * lx) + nx, fmaf(ly, B.y, T.y * lx) + ny, fmaf(ly, B.z, T.z * lx) + nz);
+}
+
 // GGX prefilter of one cube level.  SPLIT lanes share a texel and stride the sample table; the
 // table holds, per kept sample, the light direction in the texel's tangent frame, the two source
 // levels and their blend — all independent of the texel because N = V (prefiltermap.wgsl:124-126).
@@ -162,7 +171,7 @@ __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const P
   float r = 0, g = 0, b = 0;
   for (int i = sub; i < n_samples; i += SPLIT) {
     const PrefilterSample s = samples[i];
-    const V3 L = T * s.lx + B * s.ly + N * s.lz;
+    const V3 L = sample_to_world(T, B, N, s.lx, s.ly, s.lz);
     const float u = atan2f(L.z, L.x) * INV_ATAN_X + 0.5f;
     const float v = asinf(fminf(fmaxf(L.y, -1.0f), 1.0f)) * INV_ATAN_Y + 0.5f;
     const int w0 = max(1, hdr.w >> s.l0), h0 = max(1, hdr.h >> s.l0), w1 = max(1, hdr.w >> s.l1), h1 = max(1, hdr.h >> s.l1);
