@@ -249,6 +249,46 @@ def test_multisampled_pipeline_matches_oracle(small, sampler_index, moves):
         r.camera = small.pkg.Camera()
 
 
+@pytest.mark.parametrize("size", [(1, 1), (3, 1), (37, 19), (33, 35), (130, 74), (259, 2), (517, 291)])
+def test_ragged_target_sizes_match_oracle(small, size):
+    """Targets that are no multiple of the 32-pixel tile, the four-pixel skybox group or the 2x2 quad, odd
+    heights included, down to a single pixel: single-sample and multisampled."""
+    r = small.renderer
+    r.camera = small.pkg.Camera()
+    w0, h0 = small.width, small.height
+    r.width, r.height = size
+    small.width, small.height = size
+    try:
+        for msaa in (False, True):
+            r.msaa_options["enable"] = msaa
+            rgba, vis = small.render_gpu()
+            orgba, ovis = small.render_oracle()
+            assert vis.shape == ovis.shape and (vis == ovis).all(), (size, msaa)
+            d = np.abs(rgba.astype(np.int32) - orgba.astype(np.int32)).max(-1)
+            assert (d <= 2).mean() >= 0.995 and d.max() <= 8, (size, msaa, d.max(), (d <= 2).mean())
+            assert (rgba[..., 3] == 255).all()
+    finally:
+        r.msaa_options["enable"] = False
+        r.width, r.height = w0, h0
+        small.width, small.height = w0, h0
+
+
+def test_view_without_geometry_is_all_skybox(small):
+    """Camera turned away from the helmet: every triangle is rejected, no quad is listed, the frame is the skybox pass."""
+    r = small.renderer
+    r.camera = small.pkg.Camera()
+    r.camera.update_camera_rotation(-1800.0, 0.0)      # half a turn: the helmet is still in view from behind
+    r.camera.update_camera_target(4000.0, 0.0)         # and now panned far off to the side
+    try:
+        rgba, vis, st = r.draw_frame(want_vis=True, want_stats=True)
+        orgba, ovis = small.render_oracle()
+        assert (ovis == 0).all() and (vis == 0).all() and st.covered_pixels == 0
+        d = np.abs(rgba.astype(np.int32) - orgba.astype(np.int32)).max(-1)
+        assert d.max() <= 1 and (d > 0).mean() < 0.02      # hardware log2 / exp2 against libm pow: the last 8-bit step now and then
+    finally:
+        r.camera = small.pkg.Camera()
+
+
 def test_strips_equal_full_frame(small):
     r = small.renderer
     r.camera = small.pkg.Camera()
