@@ -41,6 +41,23 @@ def measured_traffic(kernel):
         return None
 
 
+VALU_FILE = os.path.join(ROOT, "profiles", "r01_valu.json")   # SQ_INSTS_VALU per launch, from scripts/gpu_pmc_frame.sh
+SIMDS, PEAK_CLOCK_HZ, CYCLES_PER_VALU_INSTRUCTION = 1024, 2.4e9, 4.0   # one vector instruction per SIMD every four cycles (measured)
+
+
+def valu_issue(kernels, ms):
+    """Share of the chip's vector-instruction issue slots that `kernels` fill when they take `ms` per launch:
+    counted wave-instructions x 4 cycles / (1024 SIMDs x time x 2.4 GHz).  The frame kernels are priced against
+    HBM bandwidth because the task says so; this is the limit they actually run into."""
+    try:
+        with open(VALU_FILE) as f:
+            table = json.load(f)
+        n = sum(float(table[k]["valu_wave_instructions"]) for k in kernels)
+    except (OSError, KeyError, ValueError):
+        return None
+    return {"wave_instructions": n, "frac": n * CYCLES_PER_VALU_INSTRUCTION / (SIMDS * ms * 1e-3 * PEAK_CLOCK_HZ)}
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,9 +235,11 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "resolve_surface_fast_kernel", "achieved": surf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": surf_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("resolve_surface_fast_kernel"), "algorithmic_bytes": surf_bytes,
                          "isolated": {"ms": iso_ms, "achieved": iso_gbs, "frac": iso_gbs / HBM_PEAK_GBS,
-                                      "frame_ms": iso_span.value / max(iso_frames.value - 1, 1)}},
+                                      "frame_ms": iso_span.value / max(iso_frames.value - 1, 1),
+                                      "valu_issue": valu_issue(["resolve_surface_fast_kernel"], iso_ms)}},
             "frame_roofline": {"bound": "hbm", "kernels": "all kernels of one frame (vertex, setup, raster+sky, surface); wall time per frame with the configured frames in flight", "achieved": frame_gbs,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS, "algorithmic_bytes": frame_bytes},
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS, "algorithmic_bytes": frame_bytes,
+                               "valu_issue": valu_issue(["setup_kernel", "raster_kernel", "resolve_surface_fast_kernel"], frame_ms)},
         }
 
     if not args.no_prefilter:
