@@ -319,16 +319,18 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // latency-bound and leave the chip almost idle, so each carries a slice of the tiles as extra
   // workgroups; the rasteriser shades the rest (each workgroup its own tile).
   const int n_tiles = tiles_x * tiles_y;
-  static const float share_vertex = getenv("PBR_SKY_SHARE_VERTEX") ? (float)atof(getenv("PBR_SKY_SHARE_VERTEX")) : 0.15f;
-  static const float share_setup = getenv("PBR_SKY_SHARE_SETUP") ? (float)atof(getenv("PBR_SKY_SHARE_SETUP")) : 0.40f;
+  // Skybox tiles that ride in the setup launch; the rasteriser's launch shades the rest.  With one frame at a time
+  // a little over half is best (the setup kernel is the longer wait); with three frames in flight, where the
+  // other frames fill that wait anyway, a third is (62.5 against 65.2 us per 4K frame).  PBR_SKY_SHARE_SETUP
+  // overrides it for measurements.
+  static const float share_setup = getenv("PBR_SKY_SHARE_SETUP") ? (float)atof(getenv("PBR_SKY_SHARE_SETUP")) : 0.35f;
   // A frame has no vertex launch: the setup kernel transforms each triangle's vertices from the streams itself
-  // and leaves a shading record per triangle, which is all the resolve kernels read.  (PBR_SKY_SHARE_VERTEX
-  // dates from a separate vertex launch; its tiles now ride in the setup launch as well.)
+  // and leaves a shading record per triangle, which is all the resolve kernels read.
   // The multisampled resolve blends over the skybox colour, which therefore has to be complete before the
   // rasteriser: all its tiles ride in the setup launch.
   SkyShare sky_b;
   sky_b.sky = pr->sky_b.cube; sky_b.rgba8 = reinterpret_cast<uint32_t*>(color); sky_b.first = 0; sky_b.own_blocks = 0;
-  sky_b.count = msaa ? n_tiles : std::min(n_tiles, (int)(n_tiles * (share_vertex + share_setup)));
+  sky_b.count = msaa ? n_tiles : std::min(n_tiles, std::max(0, (int)(n_tiles * share_setup)));
   const int sky_from_tile = sky_b.first + sky_b.count;
   const VertexSource source = {nullptr, c->d_vsoa, c->d_inst_model, c->d_inst_normal};
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));

@@ -380,7 +380,9 @@ PBR_DEV uint32_t shade_owned(const FrameParams* p, const ResolveInputs& in, cons
   const float a = roughness * roughness, a2 = a * a;
   const float rk = roughness + 1.0f, k = (rk * rk) * 0.125f;
   const float g_v = smith_ggx(ndotv, k);
+  // kD * albedo / PI of shader.wgsl:131-138 without its light-dependent factor (1 - F): the same for the four lights
   const float inv_pi = 1.0f / PI_F;
+  const V3 lambert = v3(om * albedo.x * inv_pi, om * albedo.y * inv_pi, om * albedo.z * inv_pi);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const V3 to_light = v3(p->u.light_pos[i][0], p->u.light_pos[i][1], p->u.light_pos[i][2]) - f.pos;
@@ -397,11 +399,10 @@ PBR_DEV uint32_t shade_owned(const FrameParams* p, const ResolveInputs& in, cons
     const float ndotl = fmaxf(dot(normal, light_dir), 0.0f);
     const float G = g_v * smith_ggx(ndotl, k);
     const float dg = D * G * rcp_fast(4.0f * ndotv * ndotl + 0.001f);
-    const V3 kD = v3((1.0f - F.x) * om, (1.0f - F.y) * om, (1.0f - F.z) * om);
     const float sc = attenuation * ndotl;
-    Lo.x += (kD.x * albedo.x * inv_pi + dg * F.x) * (p->u.light_color[i][0] * sc);
-    Lo.y += (kD.y * albedo.y * inv_pi + dg * F.y) * (p->u.light_color[i][1] * sc);
-    Lo.z += (kD.z * albedo.z * inv_pi + dg * F.z) * (p->u.light_color[i][2] * sc);
+    Lo.x += ((1.0f - F.x) * lambert.x + dg * F.x) * (p->u.light_color[i][0] * sc);
+    Lo.y += ((1.0f - F.y) * lambert.y + dg * F.y) * (p->u.light_color[i][1] * sc);
+    Lo.z += ((1.0f - F.z) * lambert.z + dg * F.z) * (p->u.light_color[i][2] * sc);
   }
 
   // image-based lighting (shader.wgsl:141-153)
@@ -703,7 +704,9 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   const float a = roughness * roughness, a2 = a * a;
   const float rk = roughness + 1.0f, k = (rk * rk) * 0.125f;
   const float g_v = smith_ggx(ndotv, k);
+  // kD * albedo / PI of shader.wgsl:131-138 without its light-dependent factor (1 - F): the same for the four lights
   const float inv_pi = 1.0f / PI_F;
+  const V3 lambert = v3(om * albedo.x * inv_pi, om * albedo.y * inv_pi, om * albedo.z * inv_pi);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const V3 to_light = v3(p->u.light_pos[i][0], p->u.light_pos[i][1], p->u.light_pos[i][2]) - f.pos;
@@ -719,9 +722,9 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
     const float ndotl = fmaxf(dot(normal, light_dir), 0.0f);
     const float dg = D * (g_v * smith_ggx(ndotl, k)) * rcp_fast(4.0f * ndotv * ndotl + 0.001f);
     const float sc = (inv_dist * inv_dist) * ndotl;
-    Lo.x += ((1.0f - F.x) * om * albedo.x * inv_pi + dg * F.x) * (p->u.light_color[i][0] * sc);
-    Lo.y += ((1.0f - F.y) * om * albedo.y * inv_pi + dg * F.y) * (p->u.light_color[i][1] * sc);
-    Lo.z += ((1.0f - F.z) * om * albedo.z * inv_pi + dg * F.z) * (p->u.light_color[i][2] * sc);
+    Lo.x += ((1.0f - F.x) * lambert.x + dg * F.x) * (p->u.light_color[i][0] * sc);
+    Lo.y += ((1.0f - F.y) * lambert.y + dg * F.y) * (p->u.light_color[i][1] * sc);
+    Lo.z += ((1.0f - F.z) * lambert.z + dg * F.z) * (p->u.light_color[i][2] * sc);
   }
   const float fcw = pow5(clamp01(1.0f - ndotv));
   const float omr = 1.0f - roughness;
