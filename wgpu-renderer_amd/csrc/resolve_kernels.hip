@@ -568,18 +568,23 @@ __global__ void __launch_bounds__(256) resolve_surface_msaa_kernel(const FramePa
 // record, all material texels (own pixel and helpers), all IBL texels — instead of one per lookup:
 // each set costs a memory latency, so their number sets the time a wavefront needs per item.
 // ---------------------------------------------------------------------------------------------
+// Red and green of the four taps are blended as one two-wide chain (the converted bytes are free to sit in register
+// pairs), blue on its own: each channel sees the operations, in the order, of the general kernel's lookup.
 template <bool SRGB>
 PBR_DEV V3 decode_fast(const uint32_t t[4], const Footprint& f, const float* s_srgb) {
   V3 r;
   if constexpr (SRGB) {
-    r.x = ((s_srgb[t[0] & 255u] * f.w00 + s_srgb[t[1] & 255u] * f.w10) + s_srgb[t[2] & 255u] * f.w01) + s_srgb[t[3] & 255u] * f.w11;
-    r.y = ((s_srgb[(t[0] >> 8) & 255u] * f.w00 + s_srgb[(t[1] >> 8) & 255u] * f.w10) + s_srgb[(t[2] >> 8) & 255u] * f.w01) + s_srgb[(t[3] >> 8) & 255u] * f.w11;
+    const f2 rg = (((f2){s_srgb[t[0] & 255u], s_srgb[(t[0] >> 8) & 255u]} * f.w00 + (f2){s_srgb[t[1] & 255u], s_srgb[(t[1] >> 8) & 255u]} * f.w10) +
+                   (f2){s_srgb[t[2] & 255u], s_srgb[(t[2] >> 8) & 255u]} * f.w01) + (f2){s_srgb[t[3] & 255u], s_srgb[(t[3] >> 8) & 255u]} * f.w11;
+    r.x = rg.x; r.y = rg.y;
     r.z = ((s_srgb[(t[0] >> 16) & 255u] * f.w00 + s_srgb[(t[1] >> 16) & 255u] * f.w10) + s_srgb[(t[2] >> 16) & 255u] * f.w01) + s_srgb[(t[3] >> 16) & 255u] * f.w11;
   } else {
     const float k = 1.0f / 255.0f;
+    // green and blue as the pair: the metallic-roughness lookup reads exactly those two
+    const f2 gb = ((((f2){(float)((t[0] >> 8) & 255u), (float)((t[0] >> 16) & 255u)} * f.w00 + (f2){(float)((t[1] >> 8) & 255u), (float)((t[1] >> 16) & 255u)} * f.w10) +
+                    (f2){(float)((t[2] >> 8) & 255u), (float)((t[2] >> 16) & 255u)} * f.w01) + (f2){(float)((t[3] >> 8) & 255u), (float)((t[3] >> 16) & 255u)} * f.w11) * k;
     r.x = ((((float)(t[0] & 255u) * f.w00 + (float)(t[1] & 255u) * f.w10) + (float)(t[2] & 255u) * f.w01) + (float)(t[3] & 255u) * f.w11) * k;
-    r.y = ((((float)((t[0] >> 8) & 255u) * f.w00 + (float)((t[1] >> 8) & 255u) * f.w10) + (float)((t[2] >> 8) & 255u) * f.w01) + (float)((t[3] >> 8) & 255u) * f.w11) * k;
-    r.z = ((((float)((t[0] >> 16) & 255u) * f.w00 + (float)((t[1] >> 16) & 255u) * f.w10) + (float)((t[2] >> 16) & 255u) * f.w01) + (float)((t[3] >> 16) & 255u) * f.w11) * k;
+    r.y = gb.x; r.z = gb.y;
   }
   if (f.nan) { const float n = __int_as_float(0x7fc00000); r = v3(n, n, n); }
   return r;
@@ -707,24 +712,44 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   // kD * albedo / PI of shader.wgsl:131-138 without its light-dependent factor (1 - F): the same for the four lights
   const float inv_pi = 1.0f / PI_F;
   const V3 lambert = v3(om * albedo.x * inv_pi, om * albedo.y * inv_pi, om * albedo.z * inv_pi);
+  // The four lights two at a time: element k of every two-wide value belongs to light i + k, and goes through exactly
+  // the operations of the one-light loop of the general kernel (shader.wgsl:118-139), so the results are the same bits;
+  // the sum over the lights is taken in the shader's order.
+  const float a2m1 = a2 - 1.0f, omk = 1.0f - k, four_ndotv = 4.0f * ndotv;
+  const V3 omf0 = v3(1.0f - f0.x, 1.0f - f0.y, 1.0f - f0.z);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const V3 to_light = v3(p->u.light_pos[i][0], p->u.light_pos[i][1], p->u.light_pos[i][2]) - f.pos;
-    const float dist2 = dot(to_light, to_light), inv_dist = rsq_fast(dist2);
-    const V3 light_dir = to_light * inv_dist;
-    const V3 halfway = normalize_fast(view_dir + light_dir);
-    const float ndoth = fmaxf(dot(normal, halfway), 0.0f);
-    float denom = ndoth * ndoth * (a2 - 1.0f) + 1.0f;
+  for (int i = 0; i < 4; i += 2) {
+    const f2 tlx = (f2){p->u.light_pos[i][0], p->u.light_pos[i + 1][0]} - f.pos.x, tly = (f2){p->u.light_pos[i][1], p->u.light_pos[i + 1][1]} - f.pos.y,
+             tlz = (f2){p->u.light_pos[i][2], p->u.light_pos[i + 1][2]} - f.pos.z;
+    const f2 dist2 = tlx * tlx + tly * tly + tlz * tlz;
+    const f2 inv_dist = {rsq_fast(dist2.x), rsq_fast(dist2.y)};
+    const f2 ldx = tlx * inv_dist, ldy = tly * inv_dist, ldz = tlz * inv_dist;
+    const f2 hx = view_dir.x + ldx, hy = view_dir.y + ldy, hz = view_dir.z + ldz;
+    const f2 hh = hx * hx + hy * hy + hz * hz;
+    const f2 hr = {rsq_fast(hh.x), rsq_fast(hh.y)};
+    const f2 hnx = hx * hr, hny = hy * hr, hnz = hz * hr;
+    const f2 nh = normal.x * hnx + normal.y * hny + normal.z * hnz;
+    const f2 ndoth = {fmaxf(nh.x, 0.0f), fmaxf(nh.y, 0.0f)};
+    f2 denom = ndoth * ndoth * a2m1 + 1.0f;
     denom = PI_F * denom * denom;
-    const float D = a2 * rcp_fast(denom);
-    const float fcw = pow5(clamp01(1.0f - fmaxf(dot(halfway, view_dir), 0.0f)));
-    const V3 F = v3(f0.x + (1.0f - f0.x) * fcw, f0.y + (1.0f - f0.y) * fcw, f0.z + (1.0f - f0.z) * fcw);
-    const float ndotl = fmaxf(dot(normal, light_dir), 0.0f);
-    const float dg = D * (g_v * smith_ggx(ndotl, k)) * rcp_fast(4.0f * ndotv * ndotl + 0.001f);
-    const float sc = (inv_dist * inv_dist) * ndotl;
-    Lo.x += ((1.0f - F.x) * lambert.x + dg * F.x) * (p->u.light_color[i][0] * sc);
-    Lo.y += ((1.0f - F.y) * lambert.y + dg * F.y) * (p->u.light_color[i][1] * sc);
-    Lo.z += ((1.0f - F.z) * lambert.z + dg * F.z) * (p->u.light_color[i][2] * sc);
+    const f2 D = a2 * (f2){rcp_fast(denom.x), rcp_fast(denom.y)};
+    const f2 hv = hnx * view_dir.x + hny * view_dir.y + hnz * view_dir.z;
+    const f2 omhv = 1.0f - (f2){fmaxf(hv.x, 0.0f), fmaxf(hv.y, 0.0f)};
+    const f2 cl = {clamp01(omhv.x), clamp01(omhv.y)};
+    const f2 cl2 = cl * cl, fcw2 = cl2 * cl2 * cl;
+    const f2 Fx = f0.x + omf0.x * fcw2, Fy = f0.y + omf0.y * fcw2, Fz = f0.z + omf0.z * fcw2;
+    const f2 nl = normal.x * ldx + normal.y * ldy + normal.z * ldz;
+    const f2 ndotl = {fmaxf(nl.x, 0.0f), fmaxf(nl.y, 0.0f)};
+    const f2 gden = ndotl * omk + k;
+    const f2 g_l = ndotl * (f2){rcp_fast(gden.x), rcp_fast(gden.y)};
+    const f2 sden = four_ndotv * ndotl + 0.001f;
+    const f2 dg = D * (g_v * g_l) * (f2){rcp_fast(sden.x), rcp_fast(sden.y)};
+    const f2 sc = (inv_dist * inv_dist) * ndotl;
+    const f2 tx_ = ((1.0f - Fx) * lambert.x + dg * Fx), ty_ = ((1.0f - Fy) * lambert.y + dg * Fy), tz_ = ((1.0f - Fz) * lambert.z + dg * Fz);
+    const f2 cx = (f2){p->u.light_color[i][0], p->u.light_color[i + 1][0]} * sc, cy = (f2){p->u.light_color[i][1], p->u.light_color[i + 1][1]} * sc,
+             cz = (f2){p->u.light_color[i][2], p->u.light_color[i + 1][2]} * sc;
+    Lo.x += tx_.x * cx.x; Lo.y += ty_.x * cy.x; Lo.z += tz_.x * cz.x;
+    Lo.x += tx_.y * cx.y; Lo.y += ty_.y * cy.y; Lo.z += tz_.y * cz.y;
   }
   const float fcw = pow5(clamp01(1.0f - ndotv));
   const float omr = 1.0f - roughness;
