@@ -568,6 +568,20 @@ __global__ void __launch_bounds__(256) resolve_surface_msaa_kernel(const FramePa
 // record, all material texels (own pixel and helpers), all IBL texels — instead of one per lookup:
 // each set costs a memory latency, so their number sets the time a wavefront needs per item.
 // ---------------------------------------------------------------------------------------------
+// A colour as red|green in one register pair and blue alone: channel-wise arithmetic then takes two instructions
+// instead of three, each channel seeing the operations it would see written out one by one.
+struct P3 { f2 rg; float b; };
+PBR_DEV P3 p3(V3 v) { return P3{(f2){v.x, v.y}, v.z}; }
+PBR_DEV P3 p3(float x, float y, float z) { return P3{(f2){x, y}, z}; }
+PBR_DEV P3 p3s(float v) { return P3{(f2){v, v}, v}; }
+PBR_DEV P3 operator+(P3 a, P3 b) { return P3{a.rg + b.rg, a.b + b.b}; }
+PBR_DEV P3 operator-(P3 a, P3 b) { return P3{a.rg - b.rg, a.b - b.b}; }
+PBR_DEV P3 operator*(P3 a, P3 b) { return P3{a.rg * b.rg, a.b * b.b}; }
+PBR_DEV P3 operator*(P3 a, float k) { return P3{a.rg * k, a.b * k}; }
+PBR_DEV P3 operator+(P3 a, float k) { return P3{a.rg + k, a.b + k}; }
+PBR_DEV P3 operator-(float k, P3 a) { return P3{k - a.rg, k - a.b}; }
+PBR_DEV P3 max_s(float k, P3 a) { return P3{(f2){fmaxf(k, a.rg.x), fmaxf(k, a.rg.y)}, fmaxf(k, a.b)}; }
+
 // Red and green of the four taps are blended as one two-wide chain (the converted bytes are free to sit in register
 // pairs), blue on its own: each channel sees the operations, in the order, of the general kernel's lookup.
 template <bool SRGB>
@@ -699,24 +713,26 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   const uint32_t u00 = lt[(uint32_t)ly0 * ls + lx0], u10 = lt[(uint32_t)ly0 * ls + lx1], u01 = lt[(uint32_t)ly1 * ls + lx0], u11 = lt[(uint32_t)ly1 * ls + lx1];
 
   // the rest of fs_main (shader.wgsl:95, :108-159)
-  const V3 albedo = decode_fast<true>(t_alb, fp, s_srgb);
-  const V3 em = decode_fast<true>(t_emi, fp, s_srgb);
-  const V3 emissive = v3(em.x * p->u.emissive_factor[0], em.y * p->u.emissive_factor[1], em.z * p->u.emissive_factor[2]);
+  const P3 albedo = p3(decode_fast<true>(t_alb, fp, s_srgb));
+  const P3 emissive = p3(decode_fast<true>(t_emi, fp, s_srgb)) * p3(p->u.emissive_factor[0], p->u.emissive_factor[1], p->u.emissive_factor[2]);
   const float occlusion = decode_fast<false>(t_occ, fp, s_srgb).x;
   const float om = 1.0f - metalness;
-  const V3 f0 = v3(0.04f * om + albedo.x * metalness, 0.04f * om + albedo.y * metalness, 0.04f * om + albedo.z * metalness);
+  const P3 f0c = p3s(0.04f * om) + albedo * metalness;
+  const V3 f0 = v3(f0c.rg.x, f0c.rg.y, f0c.b);
   V3 Lo = v3(0, 0, 0);
   const float a = roughness * roughness, a2 = a * a;
   const float rk = roughness + 1.0f, k = (rk * rk) * 0.125f;
   const float g_v = smith_ggx(ndotv, k);
   // kD * albedo / PI of shader.wgsl:131-138 without its light-dependent factor (1 - F): the same for the four lights
   const float inv_pi = 1.0f / PI_F;
-  const V3 lambert = v3(om * albedo.x * inv_pi, om * albedo.y * inv_pi, om * albedo.z * inv_pi);
+  const P3 lambert_c = albedo * om * inv_pi;
+  const V3 lambert = v3(lambert_c.rg.x, lambert_c.rg.y, lambert_c.b);
   // The four lights two at a time: element k of every two-wide value belongs to light i + k, and goes through exactly
   // the operations of the one-light loop of the general kernel (shader.wgsl:118-139), so the results are the same bits;
   // the sum over the lights is taken in the shader's order.
   const float a2m1 = a2 - 1.0f, omk = 1.0f - k, four_ndotv = 4.0f * ndotv;
-  const V3 omf0 = v3(1.0f - f0.x, 1.0f - f0.y, 1.0f - f0.z);
+  const P3 omf0c = 1.0f - f0c;
+  const V3 omf0 = v3(omf0c.rg.x, omf0c.rg.y, omf0c.b);
 #pragma unroll
   for (int i = 0; i < 4; i += 2) {
     const f2 tlx = (f2){p->u.light_pos[i][0], p->u.light_pos[i + 1][0]} - f.pos.x, tly = (f2){p->u.light_pos[i][1], p->u.light_pos[i + 1][1]} - f.pos.y,
@@ -753,25 +769,25 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   }
   const float fcw = pow5(clamp01(1.0f - ndotv));
   const float omr = 1.0f - roughness;
-  const V3 kS = v3(f0.x + (fmaxf(omr, f0.x) - f0.x) * fcw, f0.y + (fmaxf(omr, f0.y) - f0.y) * fcw, f0.z + (fmaxf(omr, f0.z) - f0.z) * fcw);
-  const V3 kD = v3((1.0f - kS.x) * om, (1.0f - kS.y) * om, (1.0f - kS.z) * om);
+  const P3 kS = f0c + (max_s(omr, f0c) - f0c) * fcw;
+  const P3 kD = (1.0f - kS) * om;
   const float nanv = __int_as_float(0x7fc00000);
   V3 irr = weigh4(ti, fi.w);
   if (bad_n) irr = v3(nanv, nanv, nanv);
-  const V3 pa = weigh4(ta, fa.w), pb = weigh4(tb, fb.w);
-  V3 pf = (lf == 0.0f || l1 == l0) ? pa : v3(pa.x * (1.0f - lf) + pb.x * lf, pa.y * (1.0f - lf) + pb.y * lf, pa.z * (1.0f - lf) + pb.z * lf);
-  if (bad_r) pf = v3(nanv, nanv, nanv);
+  const P3 pa = p3(weigh4(ta, fa.w)), pb = p3(weigh4(tb, fb.w));
+  const P3 pl = pa * (1.0f - lf) + pb * lf;
+  const bool one_level = lf == 0.0f || l1 == l0;
+  P3 pf = P3{(f2){one_level ? pa.rg.x : pl.rg.x, one_level ? pa.rg.y : pl.rg.y}, one_level ? pa.b : pl.b};
+  if (bad_r) pf = p3s(nanv);
   const float w00 = (1.0f - la) * (1.0f - lb), w10 = la * (1.0f - lb), w01 = (1.0f - la) * lb, w11 = la * lb;
   // NaN texels (column 0 of the table) poison the result even at zero weight: 0 * NaN = NaN
-  auto lo = [](uint32_t v) { return __half2float(__ushort_as_half((unsigned short)(v & 0xffffu))); };
-  auto hi = [](uint32_t v) { return __half2float(__ushort_as_half((unsigned short)(v >> 16))); };
-  float bx = ((lo(u00) * w00 + lo(u10) * w10) + lo(u01) * w01) + lo(u11) * w11;
-  float by = ((hi(u00) * w00 + hi(u10) * w10) + hi(u01) * w01) + hi(u11) * w11;
-  if (bad_lut) { bx = nanv; by = nanv; }
-  const V3 specular = v3(pf.x * (kS.x * bx + by), pf.y * (kS.y * bx + by), pf.z * (kS.z * bx + by));
-  const V3 ambient = v3((kD.x * irr.x * albedo.x + specular.x) * occlusion, (kD.y * irr.y * albedo.y + specular.y) * occlusion,
-                        (kD.z * irr.z * albedo.z + specular.z) * occlusion);
-  if (cov) rgba8[o] = pack_color(v3(ambient.x + Lo.x + emissive.x, ambient.y + Lo.y + emissive.y, ambient.z + Lo.z + emissive.z));
+  auto ab = [](uint32_t v) { return (f2){__half2float(__ushort_as_half((unsigned short)(v & 0xffffu))), __half2float(__ushort_as_half((unsigned short)(v >> 16)))}; };
+  f2 brdf = ((ab(u00) * w00 + ab(u10) * w10) + ab(u01) * w01) + ab(u11) * w11;
+  if (bad_lut) brdf = (f2){nanv, nanv};
+  const P3 specular = pf * (kS * brdf.x + brdf.y);
+  const P3 ambient = (kD * p3(irr) * albedo + specular) * occlusion;
+  const P3 color = ambient + p3(Lo) + emissive;
+  if (cov) rgba8[o] = pack_color(v3(color.rg.x, color.rg.y, color.b));
 }
 
 // Work list driven: the rasteriser leaves two lists of 2x2 pixel quads that hold geometry, and background
