@@ -83,6 +83,20 @@ def test_ibl_maps_match_oracle(small):
     assert (lut[ok] == ref[ok]).mean() > 0.99
 
 
+def test_ibl_maps_from_an_odd_sized_hdr():
+    """An equirect image whose sides are no powers of two (levels of 2200x1100 halve with a remainder): the
+    prefilter then takes its general path for the coarser of a sample's two source levels."""
+    s = pu.SmallScene.build(width=64, height=36, hdr_size=(2200, 1100), sky_size=32, pre_size=32, pre_mips=4, lut_size=16, irr_size=4)
+    try:
+        lib, r, m = s.pkg._lib, s.renderer, s.oracle.maps()
+        assert (r.download_map(lib.MAP_SKYBOX) == m["sky"]).all(axis=-1).mean() >= 0.999
+        assert_map_close(r.download_map(lib.MAP_IRRADIANCE), m["irr"], "irradiance", share=5e-3)
+        for lvl in range(4):
+            assert_map_close(r.download_map(lib.MAP_PREFILTER, lvl), m["pre"][lvl], f"prefilter level {lvl}", share=2e-3)
+    finally:
+        s.renderer.close()
+
+
 def test_hdr_mip_chain_matches_oracle(small):
     lib, r, o = small.pkg._lib, small.renderer, small.oracle
     for lvl in (1, 2, 5, 11):

@@ -155,7 +155,7 @@ PBR_DEV V3 sample_to_world(const V3& T, const V3& B, const V3& N, float lx, floa
 // GGX prefilter of one cube level.  SPLIT lanes share a texel and stride the sample table; the
 // table holds, per kept sample, the light direction in the texel's tangent frame, the two source
 // levels and their blend — all independent of the texel because N = V (prefiltermap.wgsl:124-126).
-template <int SPLIT>
+template <int SPLIT, bool POW2>
 __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples,
                                                         float total_weight, float4* __restrict__ out, int size, long long first, long long count) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -175,10 +175,17 @@ __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const P
     const float u = atan2f(L.z, L.x) * INV_ATAN_X + 0.5f;
     const float v = asinf(fminf(fmaxf(L.y, -1.0f), 1.0f)) * INV_ATAN_Y + 0.5f;
     const int w0 = max(1, hdr.w >> s.l0), h0 = max(1, hdr.h >> s.l0), w1 = max(1, hdr.w >> s.l1), h1 = max(1, hdr.h >> s.l1);
-    const int x0 = min((int)(u * (float)w0), w0 - 1), y0 = min((int)(v * (float)h0), h0 - 1);
-    const int x1 = min((int)(u * (float)w1), w1 - 1), y1 = min((int)(v * (float)h1), h1 - 1);
-    const float4 a = hdr.base[hdr.off[s.l0] + (uint32_t)max(y0, 0) * (uint32_t)w0 + (uint32_t)max(x0, 0)];
-    const float4 c = hdr.base[hdr.off[s.l1] + (uint32_t)max(y1, 0) * (uint32_t)w1 + (uint32_t)max(x1, 0)];
+    const int x0 = max(min((int)(u * (float)w0), w0 - 1), 0), y0 = max(min((int)(v * (float)h0), h0 - 1), 0);
+    int x1, y1;
+    if constexpr (POW2) {
+      // power-of-two source: a level's size is the previous one's half, scaling u by it is exact, and the pixel
+      // of the coarser level (l1 >= l0) is the finer level's pixel shifted down - the same integers as below
+      x1 = x0 >> (s.l1 - s.l0); y1 = min(y0 >> (s.l1 - s.l0), h1 - 1);
+    } else {
+      x1 = max(min((int)(u * (float)w1), w1 - 1), 0); y1 = max(min((int)(v * (float)h1), h1 - 1), 0);
+    }
+    const float4 a = hdr.base[hdr.off[s.l0] + (uint32_t)y0 * (uint32_t)w0 + (uint32_t)x0];
+    const float4 c = hdr.base[hdr.off[s.l1] + (uint32_t)y1 * (uint32_t)w1 + (uint32_t)x1];
     const float wa = (1.0f - s.mix) * s.lz, wc = s.mix * s.lz;
     r += a.x * wa + c.x * wc; g += a.y * wa + c.y * wc; b += a.z * wa + c.z * wc;
   }
@@ -266,19 +273,26 @@ void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int 
 void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, float total_weight,
                       float4* out_level, int level_size, int64_t first, int64_t count) {
   if (count <= 0) return;
+  const bool pow2 = (hdr.w & (hdr.w - 1)) == 0 && (hdr.h & (hdr.h - 1)) == 0;
   // Few texels: spread each texel's samples over a whole wave so the chip still fills.
   if (count >= (1 << 18)) {
     long long threads = count;
-    hipLaunchKernelGGL(prefilter_kernel<1>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
-                       out_level, level_size, (long long)first, (long long)count);
+    if (pow2) hipLaunchKernelGGL((prefilter_kernel<1, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+                                 out_level, level_size, (long long)first, (long long)count);
+    else hipLaunchKernelGGL((prefilter_kernel<1, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+                            out_level, level_size, (long long)first, (long long)count);
   } else if (count >= (1 << 14)) {
     long long threads = count * 8;
-    hipLaunchKernelGGL(prefilter_kernel<8>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
-                       out_level, level_size, (long long)first, (long long)count);
+    if (pow2) hipLaunchKernelGGL((prefilter_kernel<8, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+                                 out_level, level_size, (long long)first, (long long)count);
+    else hipLaunchKernelGGL((prefilter_kernel<8, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+                            out_level, level_size, (long long)first, (long long)count);
   } else {
     long long threads = count * 64;
-    hipLaunchKernelGGL(prefilter_kernel<64>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
-                       out_level, level_size, (long long)first, (long long)count);
+    if (pow2) hipLaunchKernelGGL((prefilter_kernel<64, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+                                 out_level, level_size, (long long)first, (long long)count);
+    else hipLaunchKernelGGL((prefilter_kernel<64, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+                            out_level, level_size, (long long)first, (long long)count);
   }
 }
 
