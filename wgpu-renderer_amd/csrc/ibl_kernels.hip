@@ -169,6 +169,7 @@ __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const P
   const V3 T = normalize(cross(upv, N));
   const V3 B = cross(N, T);
   float r = 0, g = 0, b = 0;
+  const int log2w = 31 - __clz(hdr.w);   // used when POW2: width a power of two, at least the height, so every level's width is 1 << (log2w - level)
   for (int i = sub; i < n_samples; i += SPLIT) {
     const PrefilterSample s = samples[i];
     const V3 L = sample_to_world(T, B, N, s.lx, s.ly, s.lz);
@@ -177,16 +178,20 @@ __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const P
     const int w0 = max(1, hdr.w >> s.l0), h0 = max(1, hdr.h >> s.l0), w1 = max(1, hdr.w >> s.l1), h1 = max(1, hdr.h >> s.l1);
     const int x0 = max(min((int)(u * (float)w0), w0 - 1), 0), y0 = max(min((int)(v * (float)h0), h0 - 1), 0);
     int x1, y1;
+    uint32_t row0, row1;
     if constexpr (POW2) {
       // power-of-two source: a level's size is the previous one's half, scaling u by it is exact, and the pixel
       // of the coarser level (l1 >= l0) is the finer level's pixel shifted down - the same integers as below
-      x1 = x0 >> (s.l1 - s.l0); y1 = min(y0 >> (s.l1 - s.l0), h1 - 1);
+      // (and rows are a shift apart: full-rate shifts instead of quarter-rate 32-bit multiplies)
+      x1 = x0 >> (s.l1 - s.l0); y1 = y0 >> (s.l1 - s.l0);
+      row0 = (uint32_t)y0 << (log2w - s.l0); row1 = (uint32_t)y1 << (log2w - s.l1);
     } else {
       x1 = max(min((int)(u * (float)w1), w1 - 1), 0); y1 = max(min((int)(v * (float)h1), h1 - 1), 0);
+      row0 = (uint32_t)y0 * (uint32_t)w0; row1 = (uint32_t)y1 * (uint32_t)w1;
     }
-    const float4 a = hdr.base[hdr.off[s.l0] + (uint32_t)y0 * (uint32_t)w0 + (uint32_t)x0];
-    const float4 c = hdr.base[hdr.off[s.l1] + (uint32_t)y1 * (uint32_t)w1 + (uint32_t)x1];
-    const float wa = (1.0f - s.mix) * s.lz, wc = s.mix * s.lz;
+    const float4 a = hdr.base[hdr.off[s.l0] + row0 + (uint32_t)x0];
+    const float4 c = hdr.base[hdr.off[s.l1] + row1 + (uint32_t)x1];
+    const float wa = s.wa, wc = s.wc;
     r += a.x * wa + c.x * wc; g += a.y * wa + c.y * wc; b += a.z * wa + c.z * wc;
   }
 #pragma unroll
@@ -273,7 +278,7 @@ void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int 
 void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, float total_weight,
                       float4* out_level, int level_size, int64_t first, int64_t count) {
   if (count <= 0) return;
-  const bool pow2 = (hdr.w & (hdr.w - 1)) == 0 && (hdr.h & (hdr.h - 1)) == 0;
+  const bool pow2 = (hdr.w & (hdr.w - 1)) == 0 && (hdr.h & (hdr.h - 1)) == 0 && hdr.w >= hdr.h;
   // Few texels: spread each texel's samples over a whole wave so the chip still fills.
   if (count >= (1 << 18)) {
     long long threads = count;

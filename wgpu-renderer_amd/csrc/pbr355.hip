@@ -95,7 +95,7 @@ int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out,
   const uint32_t N = PBR_PREFILTER_SAMPLES;
   if (roughness == 0.0f) {
     // every sample is H = L = N with weight 1 and source level 0: one entry reproduces the sum exactly
-    PrefilterSample s = {0.0f, 0.0f, 1.0f, 0.0f, 0, std::min(1, src_levels - 1), 0.0f, 0.0f};
+    PrefilterSample s = {0.0f, 0.0f, 1.0f, 0.0f, 0, std::min(1, src_levels - 1), 1.0f, 0.0f};   // weights (1 - 0) * 1 and 0 * 1
     out[0] = s;
     *total_weight = 1.0f;
     return 1;
@@ -131,7 +131,7 @@ int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out,
     s.mix = mip - (float)m0;
     s.l0 = std::min(std::max(m0, 0), src_levels - 1);       // a level outside the chain is clamped into it
     s.l1 = std::min(std::max(m0 + 1, 0), src_levels - 1);
-    s.pad0 = s.pad1 = 0.0f;
+    s.wa = (1.0f - s.mix) * s.lz; s.wc = s.mix * s.lz;   // this file is built without FMA contraction: the kernel's former two roundings each
     out[n++] = s;
     total += ndotl;
   }

@@ -58,7 +58,7 @@ struct PrefilterSample {
   float lx, ly, lz;   // light direction; lz is also N.L, the weight
   float mix;          // blend between source levels l0 and l0+1
   int32_t l0, l1;
-  float pad0, pad1;
+  float wa, wc;       // weights of the two source texels: (1 - mix) * lz and mix * lz
 };
 
 // Snapped, front-facing triangle as the rasteriser consumes it (48 bytes).
