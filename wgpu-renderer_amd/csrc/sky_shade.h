@@ -104,8 +104,9 @@ PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int f
   f.w[0] = oma * omb; f.w[1] = a * omb; f.w[2] = oma * b; f.w[3] = a * b;
   const int i0 = min(max((int)fu.x, -1), n - 1), j0 = min(max((int)fv.x, -1), n - 1);
   const int i1 = min(max((int)fu.y, -1), n - 1), j1 = min(max((int)fv.y, -1), n - 1);
-  f.o[0] = bordered.off[0] + ((uint32_t)face0 * m + (uint32_t)(j0 + 1)) * m + (uint32_t)(i0 + 1);
-  f.o[1] = bordered.off[0] + ((uint32_t)face1 * m + (uint32_t)(j1 + 1)) * m + (uint32_t)(i1 + 1);
+  // texel index with 24-bit multiplies (full rate; face * m + row and m are far below 2^24 for any cube the library accepts)
+  f.o[0] = bordered.off[0] + __umul24(__umul24((uint32_t)face0, (uint32_t)m) + (uint32_t)(j0 + 1), (uint32_t)m) + (uint32_t)(i0 + 1);
+  f.o[1] = bordered.off[0] + __umul24(__umul24((uint32_t)face1, (uint32_t)m) + (uint32_t)(j1 + 1), (uint32_t)m) + (uint32_t)(i1 + 1);
   f.m = (uint32_t)m;
   return f;
 }
@@ -184,11 +185,15 @@ PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sk
   const CubeFootPair fa = cube_foot_pair(sky, face[0], face[1], sc01, tc01, rc01), fb = cube_foot_pair(sky, face[2], face[3], sc23, tc23, rc23);
   Rgb tap[4][4];
   const Rgb* base = reinterpret_cast<const Rgb*>(sky.base);
+  // bytes from a texel to the one below it: the same for every lane; taken through readfirstlane so that it stays one
+  // scalar that is added, not a per-lane 64-bit multiply-add (a quarter-rate instruction)
+  const size_t pitch = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fa.m * (uint32_t)sizeof(Rgb)));
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const CubeFootPair& f = k < 2 ? fa : fb;
     const Rgb* q = base + f.o[k & 1];
-    tap[k][0] = q[0]; tap[k][1] = q[1]; tap[k][2] = q[f.m]; tap[k][3] = q[f.m + 1];
+    const Rgb* below = reinterpret_cast<const Rgb*>(reinterpret_cast<const char*>(q) + pitch);
+    tap[k][0] = q[0]; tap[k][1] = q[1]; tap[k][2] = below[0]; tap[k][3] = below[1];
   }
   pack_color_pair(weigh4_of_pair<0>(tap[0], fa.w), weigh4_of_pair<1>(tap[1], fa.w), out[0], out[1]);
   pack_color_pair(weigh4_of_pair<0>(tap[2], fb.w), weigh4_of_pair<1>(tap[3], fb.w), out[2], out[3]);
