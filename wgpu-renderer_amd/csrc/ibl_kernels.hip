@@ -182,7 +182,7 @@ __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const P
     if constexpr (POW2) {
       // power-of-two source: a level's size is the previous one's half, scaling u by it is exact, and the pixel
       // of the coarser level (l1 >= l0) is the finer level's pixel shifted down - the same integers as below
-      // (and rows are a shift apart: full-rate shifts instead of quarter-rate 32-bit multiplies)
+      // (and rows are a shift apart)
       x1 = x0 >> (s.l1 - s.l0); y1 = y0 >> (s.l1 - s.l0);
       row0 = (uint32_t)y0 << (log2w - s.l0); row1 = (uint32_t)y1 << (log2w - s.l1);
     } else {

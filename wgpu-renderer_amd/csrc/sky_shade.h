@@ -104,7 +104,7 @@ PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int f
   f.w[0] = oma * omb; f.w[1] = a * omb; f.w[2] = oma * b; f.w[3] = a * b;
   const int i0 = min(max((int)fu.x, -1), n - 1), j0 = min(max((int)fv.x, -1), n - 1);
   const int i1 = min(max((int)fu.y, -1), n - 1), j1 = min(max((int)fv.y, -1), n - 1);
-  // texel index with 24-bit multiplies (full rate; face * m + row and m are far below 2^24 for any cube the library accepts)
+  // texel index with 24-bit multiply-adds (face * m + row and m are far below 2^24 for any cube the library accepts)
   f.o[0] = bordered.off[0] + __umul24(__umul24((uint32_t)face0, (uint32_t)m) + (uint32_t)(j0 + 1), (uint32_t)m) + (uint32_t)(i0 + 1);
   f.o[1] = bordered.off[0] + __umul24(__umul24((uint32_t)face1, (uint32_t)m) + (uint32_t)(j1 + 1), (uint32_t)m) + (uint32_t)(i1 + 1);
   f.m = (uint32_t)m;
@@ -186,7 +186,7 @@ PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sk
   Rgb tap[4][4];
   const Rgb* base = reinterpret_cast<const Rgb*>(sky.base);
   // bytes from a texel to the one below it: the same for every lane; taken through readfirstlane so that it stays one
-  // scalar that is added, not a per-lane 64-bit multiply-add (a quarter-rate instruction)
+  // scalar that is added rather than multiplied out again per lane
   const size_t pitch = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fa.m * (uint32_t)sizeof(Rgb)));
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
