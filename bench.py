@@ -110,13 +110,21 @@ def cpu_baseline(pkg, renderer, W, H, budget_s=12.0):
 
 def main():
     args = parse_args()
+    # RCCL takes hardware queues of its own.  With HIP's default of four per process the three frame streams then
+    # share queues and serialise (78 against 63 us per frame); eight keeps them apart (65 us).  Without RCCL four is
+    # the better setting (63 against 73 us), so the variable is only set for multi-rank runs, before HIP starts.
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PBR_BENCH_FORCE_DIST"):
+        os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("PBR_BENCH_HW_QUEUES", "8")   # the box exports 4: override, not default
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # PBR_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, barriers, reductions, the prefilter's
+    # all-gather) with a single rank, to rehearse it on a one-GPU box under torch.distributed.run
+    use_dist = world > 1 or bool(os.environ.get("PBR_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
@@ -162,19 +170,19 @@ def main():
     # the dominant kernel is timed on the first context's stream, on the first quarter (at least eight) of
     # the frames that context renders in the timed region: an event pair costs about 10 us of stream time
     pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, max(8, (args.steps + K - 1) // K // 4)))
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         step(i)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     frames, surf_total, span = C.c_int32(), C.c_float(), C.c_float()
     pkg._lib.check(r._ctx, lib.pbr_profile_end(r._ctx, C.byref(frames), C.byref(surf_total), C.byref(span)))
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -253,20 +261,20 @@ def main():
             parallel = importlib.import_module(pkg.__name__ + ".parallel")
 
             def run_prefilter():
-                if world == 1:
+                if not use_dist:
                     pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, args.prefilter_size, args.prefilter_mips, 1024, 0, 1))
                 else:
                     parallel.prefilter_sharded(r, args.prefilter_size, args.prefilter_mips, rank, world, dev)
                 torch.cuda.synchronize(dev)
             run_prefilter()                                   # allocate + warm
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             t0 = time.perf_counter()
             run_prefilter()
-            if world > 1:
+            if use_dist:
                 dist.barrier()
             ms = (time.perf_counter() - t0) * 1e3
-            if world > 1:
+            if use_dist:
                 tmax = torch.tensor([ms], dtype=torch.float64, device=dev)
                 dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
                 ms = float(tmax.item())
@@ -283,7 +291,7 @@ def main():
     if rank == 0 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(pkg, r, W, H)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
