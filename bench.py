@@ -110,11 +110,6 @@ def cpu_baseline(pkg, renderer, W, H, budget_s=12.0):
 
 def main():
     args = parse_args()
-    # RCCL takes hardware queues of its own.  With HIP's default of four per process the three frame streams then
-    # share queues and serialise (78 against 63 us per frame); eight keeps them apart (65 us).  Without RCCL four is
-    # the better setting (63 against 73 us), so the variable is only set for multi-rank runs, before HIP starts.
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("PBR_BENCH_FORCE_DIST"):
-        os.environ["GPU_MAX_HW_QUEUES"] = os.environ.get("PBR_BENCH_HW_QUEUES", "8")   # the box exports 4: override, not default
     import torch
     import torch.distributed as dist
 
@@ -124,13 +119,21 @@ def main():
     # PBR_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, barriers, reductions, the prefilter's
     # all-gather) with a single rank, to rehearse it on a one-GPU box under torch.distributed.run
     use_dist = world > 1 or bool(os.environ.get("PBR_BENCH_FORCE_DIST"))
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # The frame streams are created and used before RCCL starts, so that they hold hardware queues of their own (a
+    # process has four by default): created after it, the three streams share queues with RCCL's and their kernels
+    # serialise, 78 against 63 us per frame.
+    frame_streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.in_flight))]
+    for st in frame_streams:
+        with torch.cuda.stream(st):
+            torch.zeros(1, device=dev)
+    torch.cuda.synchronize(dev)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
 
     import __graft_entry__ as entry
     pkg = entry.load_package()
@@ -141,7 +144,7 @@ def main():
     for _ in range(K):
         r = pkg.Renderer(width=W, height=H, device=local_rank, skybox_size=args.skybox_size)
         r.init()
-        stream = torch.cuda.Stream(dev)       # a real (non-null) stream, so torch events and syncs see the kernels
+        stream = frame_streams[len(lanes)]    # a real (non-null) stream, so torch events and syncs see the kernels
         r.set_stream(stream.cuda_stream)
         lanes.append((r, stream, torch.empty((H, W, 4), dtype=torch.uint8, device=dev)))
     r = lanes[0][0]
