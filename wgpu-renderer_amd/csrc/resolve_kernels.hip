@@ -224,11 +224,34 @@ struct QuadBary {
   float iw0, iw1, iw2;          // 1 / w of the three vertices
 };
 
+// Value of lane SRC (0..3) of the caller's quad, as a DPP move: no LDS traffic, no wait.
+template <int SRC>
+PBR_DEV float quad_bcast(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SRC * 0x55, 0xf, 0xf, false));
+}
+template <int SRC>
+PBR_DEV V3 quad_bcast3(V3 v) { return v3(quad_bcast<SRC>(v.x), quad_bcast<SRC>(v.y), quad_bcast<SRC>(v.z)); }
+
 // The triangle a pixel shows, from the shading record the setup kernel wrote for it (one round of nine 16-byte
 // loads): attributes, and the barycentrics of quad (qx, qy) from the snapped vertices the rasteriser used.
+// QUAD_SHARED: the four lanes of the quad show the same triangle; its first lane fetches the record and the other
+// three take it across lanes, a quarter of the bytes through the vector memory path.
+template <bool QUAD_SHARED = false>
 PBR_DEV void load_triangle(const ResolveInputs& in, uint32_t tri_index, int qx, int qy, Tri& t, QuadBary& qb) {
   const float4* rec = reinterpret_cast<const float4*>(in.records + tri_index);
-  const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3], r4 = rec[4], r5 = rec[5], r6 = rec[6], r7 = rec[7], r8 = rec[8];
+  float4 r0, r1, r2, r3, r4, r5, r6, r7, r8;
+  if constexpr (QUAD_SHARED) {
+    float4 v[9] = {};
+    if ((threadIdx.x & 3u) == 0u) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) v[i] = rec[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v[i] = make_float4(quad_bcast<0>(v[i].x), quad_bcast<0>(v[i].y), quad_bcast<0>(v[i].z), quad_bcast<0>(v[i].w));
+    r0 = v[0]; r1 = v[1]; r2 = v[2]; r3 = v[3]; r4 = v[4]; r5 = v[5]; r6 = v[6]; r7 = v[7]; r8 = v[8];
+  } else {
+    r0 = rec[0]; r1 = rec[1]; r2 = rec[2]; r3 = rec[3]; r4 = rec[4]; r5 = rec[5]; r6 = rec[6]; r7 = rec[7]; r8 = rec[8];
+  }
   t.p0 = v3(r3.x, r3.y, r3.z); t.p1 = v3(r3.w, r4.x, r4.y); t.p2 = v3(r4.z, r4.w, r5.x);
   t.n0 = v3(r5.y, r5.z, r5.w); t.n1 = v3(r6.x, r6.y, r6.z); t.n2 = v3(r6.w, r7.x, r7.y);
   t.t0 = make_float2(r7.z, r7.w); t.t1 = make_float2(r8.x, r8.y); t.t2 = make_float2(r8.z, r8.w);
@@ -618,14 +641,6 @@ PBR_DEV void tbn_reflect(const FrameParams* p, const V3& T, const Varyings& v, V
   R = v3(r.x, r.y, -r.z);
 }
 
-// Value of lane SRC (0..3) of the caller's quad, as a DPP move: no LDS traffic, no wait.
-template <int SRC>
-PBR_DEV float quad_bcast(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SRC * 0x55, 0xf, 0xf, false));
-}
-template <int SRC>
-PBR_DEV V3 quad_bcast3(V3 v) { return v3(quad_bcast<SRC>(v.x), quad_bcast<SRC>(v.y), quad_bcast<SRC>(v.z)); }
-
 // Four consecutive lanes shade the 2x2 pixel quad at (qx, qy); `id` is the lane's own visibility entry.
 // UNIFORM: the four pixels show one triangle, so the helper invocations the derivatives need are the
 // other three lanes and their values are read across lanes.  Otherwise every covered lane evaluates
@@ -642,7 +657,7 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   const uint32_t tri_id = cov ? id - 1u : 0u;
   Tri t;
   QuadBary qb;
-  load_triangle(in, tri_id, qx, qy, t, qb);
+  load_triangle<UNIFORM>(in, tri_id, qx, qy, t, qb);
   Varyings f, h0, h1, h2;
   if constexpr (UNIFORM) {
     f = varyings_at(t, qb, qx, qy, sub & 1, sub >> 1, p->W, p->H);
