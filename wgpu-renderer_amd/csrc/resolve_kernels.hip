@@ -227,7 +227,8 @@ struct QuadBary {
 // Value of lane SRC (0..3) of the caller's quad, as a DPP move: no LDS traffic, no wait.
 template <int SRC>
 PBR_DEV float quad_bcast(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), SRC * 0x55, 0xf, 0xf, false));
+  // every lane is written (full row and bank masks) and reads a lane of its own quad, so no previous value is needed
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), SRC * 0x55, 0xf, 0xf, true));
 }
 template <int SRC>
 PBR_DEV V3 quad_bcast3(V3 v) { return v3(quad_bcast<SRC>(v.x), quad_bcast<SRC>(v.y), quad_bcast<SRC>(v.z)); }
@@ -241,7 +242,7 @@ PBR_DEV void load_triangle(const ResolveInputs& in, uint32_t tri_index, int qx, 
   const float4* rec = reinterpret_cast<const float4*>(in.records + tri_index);
   float4 r0, r1, r2, r3, r4, r5, r6, r7, r8;
   if constexpr (QUAD_SHARED) {
-    float4 v[9] = {};
+    float4 v[9];   // left unset in the other three lanes: only the first lane's values are read below
     if ((threadIdx.x & 3u) == 0u) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) v[i] = rec[i];
