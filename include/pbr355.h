@@ -114,9 +114,15 @@ int pbr_ibl_equirect_to_cube(PbrContext* ctx, int32_t size);   /* CubemapType.SK
 int pbr_ibl_irradiance(PbrContext* ctx, int32_t size);         /* CubemapType.IRRADIANCE, irradiancemap.wgsl */
 /* CubemapType.PREFILTER, prefiltermap.wgsl: mips levels with roughness mip/(mips-1) (renderer.ts:1559),
  * samples must be 1024 (SAMPLE_COUNT, prefiltermap.wgsl:3).  The texels of all mips, flattened in
- * (mip, face, y, x) order, are cut into shard_count equal ranges and only range shard_index is
- * computed; (0,1) computes everything. */
+ * (mip, face, y, x) order, are cut into shard_count ranges of equal cost (pbr_ibl_prefilter_partition)
+ * and only range shard_index is computed; (0,1) computes everything.  A texel's value does not depend
+ * on the shard that computes it. */
 int pbr_ibl_prefilter(PbrContext* ctx, int32_t size, int32_t mips, int32_t samples, int32_t shard_index, int32_t shard_count);
+/* The same filter for an arbitrary piece of the map: texels [first_texel, first_texel + texel_count) of the
+ * flattened (mip, face, y, x) order (the dispatch loop of renderer.ts:1558-1609 cut at any texel).  For drivers
+ * that balance the work themselves, e.g. from measured times; pbr_ibl_prefilter(shard, count) is this call on
+ * the range pbr_ibl_prefilter_partition gives. */
+int pbr_ibl_prefilter_texels(PbrContext* ctx, int32_t size, int32_t mips, int32_t samples, uint64_t first_texel, uint64_t texel_count);
 int pbr_ibl_brdf_lut(PbrContext* ctx, int32_t size);           /* brdf.wgsl */
 
 /* Size in bytes and dimensions of one level of a map (level 0 for single-level maps). */
@@ -130,6 +136,17 @@ int pbr_ibl_download(PbrContext* ctx, int which, int32_t level, void* out, size_
 int pbr_ibl_device_ptr(PbrContext* ctx, int which, void** dev_ptr, size_t* total_bytes);
 /* Byte range [begin,end) of the prefilter map that shard (shard_index, shard_count) writes. */
 int pbr_ibl_prefilter_shard_range(PbrContext* ctx, int32_t shard_index, int32_t shard_count, size_t* begin, size_t* end);
+/* How the per-level loop of generateCubemap (renderer.ts:1558-1609, roughness schedule :1559) is cut into
+ * shard_count pieces of equal cost: cuts[k] is the first texel of shard k in the flattened (mip, face, y, x)
+ * order and cuts[shard_count] the texel count of the whole map (shard_count + 1 entries).  A texel of level m
+ * weighs the number of the 1024 GGX samples that contribute at that level's roughness (those with N.L > 0,
+ * prefiltermap.wgsl:138; roughness 0 needs a single one) plus a small constant for the per-texel work, so level 0,
+ * three quarters of the texels and almost none of the work, does not fill most shards.  Host arithmetic only:
+ * needs neither a context nor a device. */
+int pbr_ibl_prefilter_partition(int32_t size, int32_t mips, int32_t shard_count, uint64_t* cuts);
+/* Number of the 1024 samples of prefiltermap.wgsl:131-168 that contribute (N.L > 0) at level `level` of `mips`
+ * levels: the executed work per texel, for cost models and benchmarks.  Host arithmetic only. */
+int pbr_ibl_prefilter_kept_samples(int32_t mips, int32_t level, int32_t* kept);
 
 /* ---- the frame: drawFrame's render pass, renderer.ts:1998-2013 ----
  * Renders rows [y0,y1) of a w x h target (y0,y1 even, or y1==h) with the helmet draw

@@ -471,6 +471,52 @@ def test_large_prefilter_spot_checks():
         r.close()
 
 
+def test_prefilter_bits_are_those_of_the_first_build():
+    """Kernel work on the prefilter (lane-to-texel mapping, cheaper equirect mapping, shard cuts) must not move a
+    single bit of the map: SHA-256 of every level of both benchmark configurations against the record taken from
+    the first build of the library (scripts/gpu_prefilter_hashes.py).  The record also holds the hash of the
+    synthetic sky it was made from; a host whose numpy produces another sky cannot use it."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "prefilter_r1_hashes.json")))
+    pkg = pu._pkg()
+    lib = pkg._lib
+    hdr = pkg.synthetic_sky(4096, 2048)
+    data = np.ascontiguousarray(hdr.data, dtype=np.float32)
+    if hashlib.sha256(data.tobytes()).hexdigest() != gold["hdr_sha256"]:
+        pytest.skip("this host's numpy builds a different synthetic sky than the record's")
+    r = pkg.Renderer(width=64, height=64, hdr=hdr)
+    r._open()
+    try:
+        lib.check(r._ctx, r._lib.pbr_upload_hdr(r._ctx, ob.ptr(data), hdr.width, hdr.height))
+        for key, size, mips in (("128x5", 128, 5), ("2048x10", 2048, 10)):
+            lib.check(r._ctx, r._lib.pbr_ibl_prefilter(r._ctx, size, mips, 1024, 0, 1))
+            for m in range(mips):
+                got = hashlib.sha256(np.ascontiguousarray(r.download_map(lib.MAP_PREFILTER, m)).tobytes()).hexdigest()
+                assert got == gold[key][m], (key, m)
+        # the same bits when the map is put together from eight shards, and from odd pieces cut at arbitrary texels
+        ptr, total = C.c_void_p(), C.c_size_t()
+        lib.check(r._ctx, r._lib.pbr_ibl_device_ptr(r._ctx, lib.MAP_PREFILTER, C.byref(ptr), C.byref(total)))
+        import torch
+        from wgpu_renderer_amd import parallel, sharding
+        view = parallel.device_bytes_tensor(ptr.value, total.value, torch.device("cuda", 0))
+        view.zero_(); torch.cuda.synchronize()
+        for shard in range(8):
+            lib.check(r._ctx, r._lib.pbr_ibl_prefilter(r._ctx, 2048, 10, 1024, shard, 8))
+        for m in (1, 2, 3, 6, 9):
+            assert hashlib.sha256(np.ascontiguousarray(r.download_map(lib.MAP_PREFILTER, m)).tobytes()).hexdigest() == gold["2048x10"][m], ("shards", m)
+        view.zero_(); torch.cuda.synchronize()
+        n = sharding.prefilter_total_texels(2048, 10)
+        cuts = [0, 25165824 + 1000003, 25165824 + 3 * 1048576 + 12345, 31457280 + 777, 33030144 + 65536 * 2 + 5, n]
+        for b, e in zip(cuts, cuts[1:]):
+            lib.check(r._ctx, r._lib.pbr_ibl_prefilter_texels(r._ctx, 2048, 10, 1024, b, e - b))
+        for m in (1, 2, 3, 4, 9):
+            assert hashlib.sha256(np.ascontiguousarray(r.download_map(lib.MAP_PREFILTER, m)).tobytes()).hexdigest() == gold["2048x10"][m], ("pieces", m)
+        assert r._lib.pbr_ibl_prefilter_texels(r._ctx, 2048, 10, 1024, n - 5, 6) == lib.PBR_E_ARG
+    finally:
+        r.close()
+
+
 def test_error_reporting(small):
     lib, r = small.pkg._lib, small.renderer
     u = small.uniforms()

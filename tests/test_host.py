@@ -196,12 +196,56 @@ def test_sharding_partitions(pkg):
         ranges = [sh.prefilter_shard_texels(2048, 10, r, world) for r in range(world)]
         assert ranges[0][0] == 0 and ranges[-1][1] == total
         assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
-        assert max(e - b for b, e in ranges) - min(e - b for b, e in ranges) <= 1
         for height in (4320, 2160, 721, 2):
             rows = [sh.strip_rows(height, r, world) for r in range(world)]
             assert rows[0][0] == 0 and rows[-1][1] == height
             assert all(rows[i][1] == rows[i + 1][0] for i in range(world - 1))
             assert all(y0 % 2 == 0 for y0, _ in rows)
+
+
+def kept_samples_f64(roughness, n=1024):
+    """Samples of prefiltermap.wgsl:131-168 with N.L > 0 when N = V, evaluated in float64 from the WGSL alone."""
+    i = np.arange(n, dtype=np.uint32)
+    bits = i.copy()
+    bits = (bits << 16) | (bits >> 16)
+    bits = ((bits & 0x55555555) << 1) | ((bits & 0xAAAAAAAA) >> 1)
+    bits = ((bits & 0x33333333) << 2) | ((bits & 0xCCCCCCCC) >> 2)
+    bits = ((bits & 0x0F0F0F0F) << 4) | ((bits & 0xF0F0F0F0) >> 4)
+    bits = ((bits & 0x00FF00FF) << 8) | ((bits & 0xFF00FF00) >> 8)
+    xi_y = bits.astype(np.float64) * 2.3283064365386963e-10
+    a = float(roughness) ** 2
+    cos_theta = np.sqrt((1.0 - xi_y) / (1.0 + (a * a - 1.0) * xi_y))
+    # H = (sin t cos p, sin t sin p, cos t), V = N = (0, 0, 1): L.z = 2 (V.H) H.z - 1 = 2 cos^2 t - 1
+    return int((2.0 * cos_theta * cos_theta - 1.0 > 0.0).sum())
+
+
+def test_prefilter_shards_carry_equal_cost(pkg):
+    """The shards of the large prefilter (2048^2, 10 levels) must be balanced in work, not in texels: level 0 is three
+    quarters of the texels and, at roughness 0, one sample each.  Cost model: kept samples per texel, counted here
+    in float64 independently of the library."""
+    sh = __import__("wgpu_renderer_amd.sharding", fromlist=["x"])
+    size, mips = 2048, 10
+    kept = [1 if m == 0 else kept_samples_f64(np.float32(m / (mips - 1))) for m in range(mips)]
+    lib_kept = sh.prefilter_kept_samples(mips)
+    assert lib_kept[0] == 1 and all(abs(a - b) <= 2 for a, b in zip(kept, lib_kept)), (kept, lib_kept)
+    level_texels = [6 * (size >> m) ** 2 for m in range(mips)]
+    starts = np.concatenate([[0], np.cumsum(level_texels)])
+
+    def cost(b, e):
+        return sum(max(0, min(e, int(starts[m + 1])) - max(b, int(starts[m]))) * kept[m] for m in range(mips))
+
+    for world in (2, 4, 8, 3, 7):
+        cuts = sh.prefilter_cuts(size, mips, world)
+        assert cuts[0] == 0 and cuts[-1] == sum(level_texels) and all(a < b for a, b in zip(cuts, cuts[1:]))
+        loads = [cost(b, e) for b, e in zip(cuts, cuts[1:])]
+        assert max(loads) / (sum(loads) / world) <= 1.05, (world, loads)
+        assert [sh.prefilter_shard_texels(size, mips, r, world) for r in range(world)] == list(zip(cuts, cuts[1:]))
+    # the reference's own size: five levels of 128^2
+    for world in (2, 4, 8):
+        cuts = sh.prefilter_cuts(128, 5, world)
+        assert cuts[0] == 0 and cuts[-1] == sh.prefilter_total_texels(128, 5) and all(a <= b for a, b in zip(cuts, cuts[1:]))
+    assert sh.prefilter_cuts(128, 5, 1) == [0, sh.prefilter_total_texels(128, 5)]
+    assert sh.prefilter_cuts(16, 1, 4) == [0, 384, 768, 1152, 1536]      # a single level (roughness 0): equal texel counts
 
 
 def test_gltf_loader_without_reference_limits(tmp_path, pkg):

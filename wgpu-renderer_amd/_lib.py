@@ -46,11 +46,14 @@ EXPORTS = {
     "pbr_ibl_equirect_to_cube": (C.c_int, [C.c_void_p, C.c_int32]),
     "pbr_ibl_irradiance": (C.c_int, [C.c_void_p, C.c_int32]),
     "pbr_ibl_prefilter": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "pbr_ibl_prefilter_texels": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64]),
     "pbr_ibl_brdf_lut": (C.c_int, [C.c_void_p, C.c_int32]),
     "pbr_ibl_level_info": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_size_t)]),
     "pbr_ibl_download": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_size_t]),
     "pbr_ibl_device_ptr": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "pbr_ibl_prefilter_shard_range": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "pbr_ibl_prefilter_partition": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
+    "pbr_ibl_prefilter_kept_samples": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "pbr_draw_frame": (C.c_int, [C.c_void_p, C.POINTER(FrameUniforms), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
     "pbr_draw_frame_device": (C.c_int, [C.c_void_p, C.POINTER(FrameUniforms), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
     "pbr_debug_vertex_stage": (C.c_int, [C.c_void_p, C.POINTER(FrameUniforms), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -63,6 +66,43 @@ EXPORTS = {
 _lib = None
 
 
+def _hip_runtimes_mapped():
+    """Paths of the HIP runtime libraries mapped into this process."""
+    seen = []
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                path = line.rsplit(" ", 1)[-1].strip()
+                if os.path.basename(path).startswith("libamdhip64.so") and path not in seen:
+                    seen.append(path)
+    except OSError:
+        pass
+    return seen
+
+
+def _bind_to_torch_runtime():
+    """One process must talk to the GPU through ONE HIP runtime.  libpbr355.so needs `libamdhip64.so.7`; a PyTorch
+    ROCm wheel ships its own runtime as `torch/lib/libamdhip64.so`, whose SONAME is also `libamdhip64.so.7`.  The
+    dynamic loader matches a needed library against the loaded ones by name: with torch loaded first, libpbr355.so is
+    bound to torch's copy (one runtime); with libpbr355.so loaded first, /opt/rocm's copy is mapped, torch's request
+    for `libamdhip64.so` matches neither its name nor its SONAME, and a second runtime (with a second HSA runtime
+    under it) is mapped - the one that initialises second then finds no usable GPU ("No HIP GPUs are available"),
+    and a hipStream_t of one is meaningless to the other.  So when a torch with its own runtime is installed, that
+    runtime is mapped first, globally, whether or not torch has been imported yet; both orders then end with it."""
+    import importlib.util
+    if any("torch" in p for p in _hip_runtimes_mapped()):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    bundled = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.isfile(bundled):
+        C.CDLL(bundled, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load libpbr355.so and declare every export of include/pbr355.h."""
     global _lib
@@ -70,7 +110,12 @@ def load():
         if not os.path.isfile(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _bind_to_torch_runtime()
         lib = C.CDLL(LIB_PATH)
+        runtimes = _hip_runtimes_mapped()
+        if len(runtimes) > 1:
+            raise ImportError("two HIP runtimes are mapped into this process (" + ", ".join(runtimes) + "): libpbr355.so and torch would each "
+                              "open the GPU through their own; load libpbr355 through this module before anything maps /opt/rocm's runtime")
         for name, (restype, argtypes) in EXPORTS.items():
             fn = getattr(lib, name)
             fn.restype = restype

@@ -159,10 +159,31 @@ template <int SPLIT, bool POW2>
 __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples,
                                                         float total_weight, float4* __restrict__ out, int size, long long first, long long count) {
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long local = gid / SPLIT;
-  const int sub = (int)(gid % SPLIT);
-  const bool live = local < count;
-  const long long t = first + (live ? local : 0);
+  long long t;
+  int sub;
+  bool live;
+  if constexpr (SPLIT == 1) {
+    // One texel per lane, and a wavefront is an 8 x 8 block of texels rather than a 64 x 1 strip: its 64 directions
+    // stay close together, so the source pixels of one sample fall into few cache lines on every face.  (A strip of
+    // a +-Y face fans out over a quarter turn of longitude near the pole rows of the equirect image: those faces
+    // took twice as long as the others.)  Rows are counted through the faces (face * size + y); the launch covers
+    // the 8-row bands that hold the range [first, first + count), lanes outside it idle.
+    const long long wave = gid >> 6;
+    const int lane = threadIdx.x & 63;
+    const int blocks_x = (size + 7) >> 3;
+    const long long row0 = (first / size) & ~7ll;
+    const long long row = row0 + (wave / blocks_x) * 8 + (lane >> 3);
+    const int x = (int)(wave % blocks_x) * 8 + (lane & 7);
+    const long long flat = row * size + x;
+    live = x < size && row < 6ll * size && flat >= first && flat < first + count;
+    t = live ? flat : first;
+    sub = 0;
+  } else {
+    const long long local = gid / SPLIT;
+    sub = (int)(gid % SPLIT);
+    live = local < count;
+    t = first + (live ? local : 0);
+  }
   const int gz = (int)(t / ((long long)size * size)), gy = (int)((t / size) % size), gx = (int)(t % size);
   const V3 N = texel_direction(gx, gy, gz, size);
   const V3 upv = fabsf(N.z) < 0.999f ? v3(0, 0, 1) : v3(1, 0, 0);   // prefiltermap.wgsl:56-61
@@ -279,14 +300,19 @@ void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* sam
                       float4* out_level, int level_size, int64_t first, int64_t count) {
   if (count <= 0) return;
   const bool pow2 = (hdr.w & (hdr.w - 1)) == 0 && (hdr.h & (hdr.h - 1)) == 0 && hdr.w >= hdr.h;
-  // Few texels: spread each texel's samples over a whole wave so the chip still fills.
-  if (count >= (1 << 18)) {
-    long long threads = count;
+  // Few texels: spread each texel's samples over a whole wave so the chip still fills.  The split fixes the order
+  // in which a texel's samples are summed, so it follows the size of the level, not of the range: a texel gets the
+  // same bits whichever shard computes it.
+  const long long level_texels = 6ll * level_size * level_size;
+  if (level_texels >= (1 << 18)) {
+    // 8-row bands that hold the range, one wavefront per 8 x 8 block of texels
+    const long long row0 = (first / level_size) & ~7ll, row1 = (first + count - 1) / level_size;
+    const long long threads = ((row1 - row0) / 8 + 1) * ((level_size + 7) / 8) * 64;
     if (pow2) hipLaunchKernelGGL((prefilter_kernel<1, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
                                  out_level, level_size, (long long)first, (long long)count);
     else hipLaunchKernelGGL((prefilter_kernel<1, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
                             out_level, level_size, (long long)first, (long long)count);
-  } else if (count >= (1 << 14)) {
+  } else if (level_texels >= (1 << 14)) {
     long long threads = count * 8;
     if (pow2) hipLaunchKernelGGL((prefilter_kernel<8, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
                                  out_level, level_size, (long long)first, (long long)count);

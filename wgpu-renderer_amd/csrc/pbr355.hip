@@ -139,6 +139,44 @@ int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out,
   return n;
 }
 
+// renderer.ts:1559: roughness = mip / (maxMipLevels - 1) stored as f32; a single level gets 0
+float prefilter_roughness(int level, int mips) { return mips > 1 ? (float)((double)level / (double)(mips - 1)) : 0.0f; }
+
+// Cost of one output texel of each level, in units of one kept sample: the samples the level's table keeps plus
+// a constant for the work a texel does whatever its sample count (direction, tangent frame, the 16-byte store).
+constexpr uint64_t PREFILTER_TEXEL_OVERHEAD = 8;
+void prefilter_level_costs(int mips, int* kept, uint64_t* cost) {
+  std::vector<PrefilterSample> table(PBR_PREFILTER_SAMPLES);
+  for (int m = 0; m < mips; ++m) {
+    float weight;
+    const int n = build_prefilter_table(prefilter_roughness(m, mips), PBR_MAX_LEVELS, table.data(), &weight);   // the count does not depend on the source's level count
+    if (kept) kept[m] = n;
+    if (cost) cost[m] = (uint64_t)n + PREFILTER_TEXEL_OVERHEAD;
+  }
+}
+
+// First texel (in the flattened (mip, face, y, x) order) of each of n shards of equal cost; cuts[n] = all texels.
+// The reference filters level after level (renderer.ts:1558-1609); level 0 holds three quarters of the texels
+// but, at roughness 0, almost none of the work, so equal texel counts would leave most shards idle.
+void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
+  uint64_t cost[PBR_MAX_LEVELS], texels[PBR_MAX_LEVELS], total_cost = 0, total_texels = 0;
+  prefilter_level_costs(mips, nullptr, cost);
+  for (int m = 0; m < mips; ++m) {
+    const uint64_t s = (uint64_t)std::max(1, size >> m);
+    texels[m] = 6 * s * s;
+    total_cost += texels[m] * cost[m];
+    total_texels += texels[m];
+  }
+  cuts[0] = 0; cuts[n] = total_texels;
+  for (int k = 1; k < n; ++k) {
+    const uint64_t target = (uint64_t)(((unsigned __int128)total_cost * (unsigned)k) / (unsigned)n);
+    uint64_t before_cost = 0, before_texels = 0;
+    int m = 0;
+    while (m < mips - 1 && before_cost + texels[m] * cost[m] <= target) { before_cost += texels[m] * cost[m]; before_texels += texels[m]; ++m; }
+    cuts[k] = before_texels + std::min(texels[m], (target - before_cost) / cost[m]);
+  }
+}
+
 int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int samples) {
   const size_t ntri = (size_t)(c->n_indices / 3) * c->n_instances;
   bool grew = false;
@@ -621,25 +659,44 @@ int pbr_ibl_irradiance(PbrContext* c, int32_t size) {
   return PBR_OK;
 }
 
-static void prefilter_total(const PbrContext* c, size_t* texels) { *texels = c->pre_total_texels; }
-
 int pbr_ibl_prefilter_shard_range(PbrContext* c, int32_t shard_index, int32_t shard_count, size_t* begin, size_t* end) {
   if (!c || !begin || !end) return PBR_E_ARG;
   if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail(c, PBR_E_ARG, "bad shard %d of %d", shard_index, shard_count);
   if (!c->d_pre) return fail(c, PBR_E_STATE, "prefilter map not allocated; call pbr_ibl_prefilter first");
-  size_t total;
-  prefilter_total(c, &total);
-  *begin = total * (size_t)shard_index / (size_t)shard_count * sizeof(float4);
-  *end = total * (size_t)(shard_index + 1) / (size_t)shard_count * sizeof(float4);
+  if (shard_count > PBR_MAX_SHARDS) return fail(c, PBR_E_ARG, "at most %d shards", PBR_MAX_SHARDS);
+  std::vector<uint64_t> cuts((size_t)shard_count + 1);
+  prefilter_cuts(c->pre.size, c->pre.levels, shard_count, cuts.data());
+  *begin = (size_t)cuts[shard_index] * sizeof(float4);
+  *end = (size_t)cuts[shard_index + 1] * sizeof(float4);
   return PBR_OK;
 }
 
-int pbr_ibl_prefilter(PbrContext* c, int32_t size, int32_t mips, int32_t samples, int32_t shard_index, int32_t shard_count) {
+int pbr_ibl_prefilter_partition(int32_t size, int32_t mips, int32_t shard_count, uint64_t* cuts) {
+  if (!cuts) return fail(nullptr, PBR_E_ARG, "cuts is null");
+  if (size <= 0 || size > 8192) return fail(nullptr, PBR_E_ARG, "bad cube size %d", size);
+  if (mips < 1 || mips > PBR_MAX_LEVELS || (size >> (mips - 1)) < 1) return fail(nullptr, PBR_E_ARG, "bad mip count %d for size %d", mips, size);
+  if (shard_count < 1 || shard_count > PBR_MAX_SHARDS) return fail(nullptr, PBR_E_ARG, "bad shard count %d (1..%d)", shard_count, PBR_MAX_SHARDS);
+  prefilter_cuts(size, mips, shard_count, cuts);
+  return PBR_OK;
+}
+
+int pbr_ibl_prefilter_kept_samples(int32_t mips, int32_t level, int32_t* kept) {
+  if (!kept) return fail(nullptr, PBR_E_ARG, "kept is null");
+  if (mips < 1 || mips > PBR_MAX_LEVELS || level < 0 || level >= mips) return fail(nullptr, PBR_E_ARG, "bad level %d of %d", level, mips);
+  int counts[PBR_MAX_LEVELS];
+  prefilter_level_costs(mips, counts, nullptr);
+  *kept = counts[level];
+  return PBR_OK;
+}
+
+// Filters texels [begin, end) of the flattened (mip, face, y, x) order; end == 0 stands for the whole map.
+static int prefilter_texel_range(PbrContext* c, int32_t size, int32_t mips, int32_t samples, uint64_t begin, uint64_t end, int shard_index, int shard_count) {
   if (!c) return PBR_E_ARG;
   if (size <= 0 || size > 8192) return fail(c, PBR_E_ARG, "bad cube size %d", size);
   if (mips < 1 || mips > PBR_MAX_LEVELS || (size >> (mips - 1)) < 1) return fail(c, PBR_E_ARG, "bad mip count %d for size %d", mips, size);
   if (samples != PBR_PREFILTER_SAMPLES) return fail(c, PBR_E_UNSUPPORTED, "sample count %d: the reference fixes SAMPLE_COUNT at 1024", samples);
-  if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail(c, PBR_E_ARG, "bad shard %d of %d", shard_index, shard_count);
+  if (shard_count >= 0 && (shard_count < 1 || shard_count > PBR_MAX_SHARDS || shard_index < 0 || shard_index >= shard_count))
+    return fail(c, PBR_E_ARG, "bad shard %d of %d", shard_index, shard_count);
   if (!c->d_hdr) return fail(c, PBR_E_STATE, "no HDR uploaded");
   DeviceGuard guard(c->device);
   PbrContextPrivate* pr = priv_of(c);
@@ -657,20 +714,24 @@ int pbr_ibl_prefilter(PbrContext* c, int32_t size, int32_t mips, int32_t samples
   if (pr->prefilter_tables_for != mips || pr->prefilter_src_levels != c->hdr.levels) {
     std::vector<PrefilterSample> host((size_t)PBR_PREFILTER_SAMPLES * mips);
     for (int m = 0; m < mips; ++m) {
-      // renderer.ts:1559: roughness = mip / (maxMipLevels - 1) stored as f32; a single level gets 0
-      const float roughness = mips > 1 ? (float)((double)m / (double)(mips - 1)) : 0.0f;
+      const float roughness = prefilter_roughness(m, mips);
       pr->table_count[m] = build_prefilter_table(roughness, c->hdr.levels, host.data() + (size_t)m * PBR_PREFILTER_SAMPLES, &pr->table_weight[m]);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_samples, host.data(), host.size() * sizeof(PrefilterSample), hipMemcpyHostToDevice));
     pr->prefilter_tables_for = mips; pr->prefilter_src_levels = c->hdr.levels;
   }
-  const size_t total = c->pre_total_texels;
-  const size_t begin = total * (size_t)shard_index / (size_t)shard_count, end = total * (size_t)(shard_index + 1) / (size_t)shard_count;
+  if (shard_count >= 0) {
+    std::vector<uint64_t> cuts((size_t)shard_count + 1);
+    prefilter_cuts(size, mips, shard_count, cuts.data());
+    begin = cuts[shard_index]; end = cuts[shard_index + 1];
+  } else if (begin > end || end > c->pre_total_texels) {
+    return fail(c, PBR_E_ARG, "texel range [%llu, %llu) outside the map's %zu texels", (unsigned long long)begin, (unsigned long long)end, c->pre_total_texels);
+  }
   for (int m = 0; m < mips; ++m) {
     const size_t s = (size_t)std::max(1, size >> m);
     const size_t lo = c->pre.off[m], hi = lo + 6 * s * s;
-    const size_t a = std::max(lo, begin), b = std::min(hi, end);
+    const size_t a = std::max(lo, (size_t)begin), b = std::min(hi, (size_t)end);
     if (a >= b) continue;
     launch_prefilter(c->stream, c->hdr, c->d_samples + (size_t)m * PBR_PREFILTER_SAMPLES, pr->table_count[m], pr->table_weight[m],
                      c->d_pre + lo, (int)s, (int64_t)(a - lo), (int64_t)(b - a));
@@ -678,6 +739,15 @@ int pbr_ibl_prefilter(PbrContext* c, int32_t size, int32_t mips, int32_t samples
   pr->pre_b.dirty = true;
   HIP_TRY(c, hipGetLastError());
   return PBR_OK;
+}
+
+int pbr_ibl_prefilter(PbrContext* c, int32_t size, int32_t mips, int32_t samples, int32_t shard_index, int32_t shard_count) {
+  if (shard_count < 0) return c ? fail(c, PBR_E_ARG, "bad shard %d of %d", shard_index, shard_count) : PBR_E_ARG;
+  return prefilter_texel_range(c, size, mips, samples, 0, 0, shard_index, shard_count);
+}
+
+int pbr_ibl_prefilter_texels(PbrContext* c, int32_t size, int32_t mips, int32_t samples, uint64_t first_texel, uint64_t texel_count) {
+  return prefilter_texel_range(c, size, mips, samples, first_texel, first_texel + texel_count, 0, -1);
 }
 
 int pbr_ibl_brdf_lut(PbrContext* c, int32_t size) {

@@ -11,6 +11,7 @@
 #define PBR_SUBPIXEL_BITS 8
 #define PBR_GUARD 8.0f            // guard band in units of w
 #define PBR_PREFILTER_SAMPLES 1024
+#define PBR_MAX_SHARDS 4096         // most shards the prefilter's texels can be cut into
 #define PBR_BIN_CAP 256           // triangle references a tile keeps in its own row before spilling to the overflow list
 
 // An rgba8 texture with its mip chain in one allocation.  Every level is stored in blocks of 8 x 4

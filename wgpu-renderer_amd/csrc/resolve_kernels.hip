@@ -242,7 +242,12 @@ PBR_DEV void load_triangle(const ResolveInputs& in, uint32_t tri_index, int qx, 
   const float4* rec = reinterpret_cast<const float4*>(in.records + tri_index);
   float4 r0, r1, r2, r3, r4, r5, r6, r7, r8;
   if constexpr (QUAD_SHARED) {
-    float4 v[9];   // left unset in the other three lanes: only the first lane's values are read below
+    // The other three lanes never use their own values (only the first lane's are read below), so these need no
+    // particular content - but they must be defined: each register is claimed through an empty asm statement, which
+    // costs no instruction and leaves the compiler nothing undefined to reason about.
+    float4 v[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) asm volatile("" : "=v"(v[i].x), "=v"(v[i].y), "=v"(v[i].z), "=v"(v[i].w));
     if ((threadIdx.x & 3u) == 0u) {
 #pragma unroll
       for (int i = 0; i < 9; ++i) v[i] = rec[i];

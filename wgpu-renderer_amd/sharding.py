@@ -3,11 +3,12 @@ partitions exist only where the work divides without changing any result:
 
   * orbit frames      - frame f of a camera path goes to rank f mod world (no exchange)
   * prefilter shards  - the texels of all prefilter mips, flattened in (mip, face, y, x) order,
-                        are cut into `world` equal ranges (same rule as pbr_ibl_prefilter); the
-                        ranges are exchanged with one all-gather
+                        are cut into `world` ranges of equal cost (the library's own rule,
+                        pbr_ibl_prefilter_partition); the ranges are exchanged with one all-gather
   * screen strips     - rank g owns an even-aligned band of rows; bands are gathered to rank 0
 
-Everything here is plain integer arithmetic so it can be tested without a GPU.
+Everything here is host arithmetic (the prefilter cuts come from a host-only call of the library) so
+it can be tested without a GPU.
 """
 
 
@@ -19,15 +20,39 @@ def prefilter_total_texels(size, mips):
     return sum(6 * max(1, size >> m) ** 2 for m in range(mips))
 
 
+def prefilter_cuts(size, mips, world):
+    """First texel of every shard plus the total (world + 1 numbers), from the library's own partition
+    (pbr_ibl_prefilter_partition, host arithmetic, no device needed): a texel of level m weighs the GGX
+    samples kept at that level's roughness, so the shards carry equal work, not equal texel counts."""
+    import ctypes as C
+    from . import _lib
+    cuts = (C.c_uint64 * (world + 1))()
+    _lib.check(None, _lib.load().pbr_ibl_prefilter_partition(size, mips, world, cuts))
+    return [int(x) for x in cuts]
+
+
+def prefilter_kept_samples(mips):
+    """Samples of the 1024 that contribute at each level (1 at roughness 0)."""
+    import ctypes as C
+    from . import _lib
+    out = []
+    for level in range(mips):
+        n = C.c_int32()
+        _lib.check(None, _lib.load().pbr_ibl_prefilter_kept_samples(mips, level, C.byref(n)))
+        out.append(n.value)
+    return out
+
+
 def prefilter_shard_texels(size, mips, rank, world):
     """[begin, end) in texels; identical to pbr_ibl_prefilter_shard_range / 16 bytes."""
-    total = prefilter_total_texels(size, mips)
-    return total * rank // world, total * (rank + 1) // world
+    cuts = prefilter_cuts(size, mips, world)
+    return cuts[rank], cuts[rank + 1]
 
 
 def prefilter_padded_chunk(size, mips, world):
     """All-gather needs equal chunks: the largest shard, in texels."""
-    return max(e - b for b, e in (prefilter_shard_texels(size, mips, r, world) for r in range(world)))
+    cuts = prefilter_cuts(size, mips, world)
+    return max(e - b for b, e in zip(cuts[:-1], cuts[1:]))
 
 
 def strip_rows(height, rank, world):
