@@ -9,9 +9,38 @@
 #include <cstdio>
 #include <cstring>
 
+// ---- Working memory of pbr_draw_frame_static: one fixed array per GPU instead of buffers grown with hipMalloc.
+// What a frame keeps between its three launches (append counters, tile bins, set-up triangles, shading records, the
+// two quad work lists) is laid out in it back to back.  Host code never uses the array by name: its address on each
+// device is taken once with hipGetSymbolAddress (pbr_create, with that device current) and travels as a pointer.
+#define PBR_STATIC_MAX_TILES 2048          // 32 x 32 pixel tiles of the row range, e.g. 1920 x 1080 (60 x 34 = 2040)
+#define PBR_STATIC_MAX_TRIANGLES 32768     // triangles x instances of the uploaded mesh
+namespace static_layout {
+constexpr size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr size_t kSetupCap = PBR_STATIC_MAX_TRIANGLES + PBR_STATIC_MAX_TRIANGLES / 4 + 4096;
+constexpr size_t kOverflowCap = kSetupCap * 2 + (1u << 16);
+constexpr size_t kQuads = (size_t)PBR_STATIC_MAX_TILES * (PBR_TILE / 2) * (PBR_TILE / 2);
+constexpr size_t kCounters = 0;                                                                   // 16 x u32
+constexpr size_t kTileCount = align_up(kCounters + 16 * sizeof(uint32_t));                        // [tiles] u32
+constexpr size_t kZeroedBytes = align_up(kTileCount + PBR_STATIC_MAX_TILES * sizeof(uint32_t));   // cleared at the start of every call
+constexpr size_t kBins = kZeroedBytes;                                                            // [tiles][PBR_BIN_CAP] u32
+constexpr size_t kSetup = align_up(kBins + (size_t)PBR_STATIC_MAX_TILES * PBR_BIN_CAP * sizeof(uint32_t));
+constexpr size_t kOverflow = align_up(kSetup + kSetupCap * sizeof(SetupTri));
+constexpr size_t kRecords = align_up(kOverflow + kOverflowCap * sizeof(uint2));
+constexpr size_t kUniform = align_up(kRecords + (size_t)PBR_STATIC_MAX_TRIANGLES * sizeof(TriRecord));
+constexpr size_t kMixedPos = align_up(kUniform + kQuads * sizeof(uint2));
+constexpr size_t kMixedIds = align_up(kMixedPos + kQuads * sizeof(uint32_t));
+constexpr size_t kBytes = align_up(kMixedIds + kQuads * sizeof(uint4));                           // about 24 MB
+}  // namespace static_layout
+static __device__ __align__(256) unsigned char scratch[static_layout::kBytes];
+
 namespace {
 
 thread_local std::string g_create_error;
+
+// Address of `scratch` on each device (every GPU holds its own copy of the array at its own address).
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
 
 int fail(PbrContext* ctx, int code, const char* fmt, ...) {
   char buf[512];
@@ -244,6 +273,7 @@ struct PbrContextPrivate {
   uint32_t* d_lut_pair = nullptr; int lut_pair_size = 0; bool lut_pair_dirty = true;   // two-channel copy of the BRDF table for the resolve
   int surface_blocks = 0;                 // resident workgroups of the surface kernel on this device
   int counter_set = 0;                    // which of the two sets of append counters the next frame uses
+  bool used_static = false;               // pbr_draw_frame_static has run: its overflow flag lives in the device's fixed array
 };
 static PbrContextPrivate* priv_of(PbrContext* c);
 
@@ -285,8 +315,19 @@ static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const
   return PBR_OK;
 }
 
+// The memory a frame works in between its launches: the context's own buffers (grown on demand) or, for
+// pbr_draw_frame_static, slices of the device's fixed scratch array.
+struct FrameWork {
+  SetupTri* setup; size_t setup_cap;
+  TriRecord* records;
+  uint32_t* tile_count; uint32_t* bins;
+  uint2* overflow; size_t overflow_cap;
+  QuadLists lists;
+  uint32_t* counters; uint32_t* next_counters;
+};
+
 static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, int y0, int y1, void* d_rgba8, void* d_vis, bool want_host_vis,
-                       PbrFrameStats* stats) {
+                       PbrFrameStats* stats, bool static_memory = false) {
   if (!u) return fail(c, PBR_E_ARG, "uniforms pointer is null");
   if (W <= 0 || H <= 0 || W > 16384 || H > 16384) return fail(c, PBR_E_ARG, "bad target size %dx%d", W, H);
   if (y0 < 0 || y1 > H || y0 >= y1 || (y0 & 1) || ((y1 & 1) && y1 != H)) return fail(c, PBR_E_ARG, "bad row range [%d,%d) for height %d (rows must start and end on even lines)", y0, y1, H);
@@ -306,8 +347,45 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // bit 16 of the sampler index selects the multisampled pipeline (renderer.ts:1927-1932, :1951-1954, :1979-1980)
   const bool msaa = (u->sampler_index & 16u) != 0u;
   const int samples = msaa ? 4 : 1;
-  int rc = ensure_frame_buffers(c, W, rows, tiles_x * tiles_y, samples);
-  if (rc) return rc;
+  int rc = PBR_OK;
+  FrameWork fw;
+  if (static_memory) {
+    // nothing may be allocated on this path: the frame has to fit the fixed array, and everything derived from the
+    // IBL maps has to exist already
+    using namespace static_layout;
+    const size_t ntri = (size_t)(c->n_indices / 3) * c->n_instances;
+    if (msaa) return fail(c, PBR_E_UNSUPPORTED, "pbr_draw_frame_static renders the single-sample pipeline only");
+    if (tiles_x * tiles_y > PBR_STATIC_MAX_TILES)
+      return fail(c, PBR_E_ARG, "pbr_draw_frame_static: %d x %d pixels are %d tiles of 32 x 32, the fixed working memory holds %d (e.g. 1920 x 1080)", W, rows,
+                  tiles_x * tiles_y, PBR_STATIC_MAX_TILES);
+    if (ntri > PBR_STATIC_MAX_TRIANGLES)
+      return fail(c, PBR_E_ARG, "pbr_draw_frame_static: %zu triangles (all instances), the fixed working memory holds %d", ntri, PBR_STATIC_MAX_TRIANGLES);
+    if (c->device < 0 || c->device >= kMaxDevices || !g_scratch_ptr[c->device]) return fail(c, PBR_E_STATE, "no fixed working memory on device %d", c->device);
+    if (pr->sky_b.dirty || !pr->sky_b.d || pr->irr_b.dirty || !pr->irr_b.d || pr->pre_b.dirty || !pr->pre_b.d || pr->lut_pair_dirty || pr->lut_pair_size != c->lut_size)
+      return fail(c, PBR_E_STATE, "pbr_draw_frame_static: the lookup copies of the IBL maps are not built yet; draw one frame with pbr_draw_frame_device after the last IBL call");
+    unsigned char* base = g_scratch_ptr[c->device];
+    fw.counters = reinterpret_cast<uint32_t*>(base + kCounters); fw.next_counters = fw.counters + 8;
+    fw.tile_count = reinterpret_cast<uint32_t*>(base + kTileCount);
+    fw.bins = reinterpret_cast<uint32_t*>(base + kBins);
+    fw.setup = reinterpret_cast<SetupTri*>(base + kSetup); fw.setup_cap = kSetupCap;
+    fw.overflow = reinterpret_cast<uint2*>(base + kOverflow); fw.overflow_cap = kOverflowCap;
+    fw.records = reinterpret_cast<TriRecord*>(base + kRecords);
+    fw.lists.uniform = reinterpret_cast<uint2*>(base + kUniform);
+    fw.lists.mixed_pos = reinterpret_cast<uint32_t*>(base + kMixedPos);
+    fw.lists.mixed_ids = reinterpret_cast<uint4*>(base + kMixedIds);
+    // every call on this GPU shares the array and finds the previous call's contents in it: the append counters and the
+    // per-tile reference counts must start at zero (the lists and records are written before they are read)
+    HIP_TRY(c, hipMemsetAsync(base, 0, kZeroedBytes, c->stream));
+    pr->used_static = true;
+  } else {
+    rc = ensure_frame_buffers(c, W, rows, tiles_x * tiles_y, samples);
+    if (rc) return rc;
+    fw.setup = c->d_setup; fw.setup_cap = c->setup_cap; fw.records = c->d_records; fw.tile_count = c->d_tile_count; fw.bins = c->d_bins;
+    fw.overflow = c->d_overflow; fw.overflow_cap = c->overflow_cap; fw.lists = c->quad_lists;
+    // two sets of append counters, used by alternate frames (the rasteriser re-arms the next frame's set)
+    fw.counters = c->d_counters + 8 * pr->counter_set;
+    fw.next_counters = c->d_counters + 8 * (1 - pr->counter_set);
+  }
 
   // per-frame parameters travel as kernel arguments
   FrameParams fp;
@@ -321,8 +399,8 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   const FrameParams& dp = fp;
   hipStream_t s = c->stream;
 
-  if ((rc = refresh_bordered(c, pr->sky_b, c->sky)) || (rc = refresh_bordered(c, pr->irr_b, c->irr)) || (rc = refresh_bordered(c, pr->pre_b, c->pre))) return rc;
-  if (pr->lut_pair_dirty || pr->lut_pair_size != c->lut_size) {
+  if (!static_memory && ((rc = refresh_bordered(c, pr->sky_b, c->sky)) || (rc = refresh_bordered(c, pr->irr_b, c->irr)) || (rc = refresh_bordered(c, pr->pre_b, c->pre)))) return rc;
+  if (!static_memory && (pr->lut_pair_dirty || pr->lut_pair_size != c->lut_size)) {
     if (pr->lut_pair_size != c->lut_size) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
       if (pr->d_lut_pair) { (void)hipFree(pr->d_lut_pair); pr->d_lut_pair = nullptr; }
@@ -347,11 +425,10 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     fast = fast && (c->tex[i].w & (c->tex[i].w - 1)) == 0 && (c->tex[i].h & (c->tex[i].h - 1)) == 0 && c->tex[i].w == c->tex[0].w &&
            c->tex[i].h == c->tex[0].h && c->tex[i].levels == c->tex[0].levels;
 
-  // two sets of append counters, used by alternate frames (the rasteriser re-arms the next frame's set)
-  uint32_t* counters = c->d_counters + 8 * pr->counter_set;
-  uint32_t* next_counters = c->d_counters + 8 * (1 - pr->counter_set);
+  uint32_t* counters = fw.counters;
+  uint32_t* next_counters = fw.next_counters;
   const int this_set = pr->counter_set;
-  pr->counter_set = 1 - pr->counter_set;
+  if (!static_memory) pr->counter_set = 1 - pr->counter_set;
 
   // The skybox tiles are shared out over the frame's geometry launches: those kernels are
   // latency-bound and leave the chip almost idle, so each carries a slice of the tiles as extra
@@ -372,30 +449,30 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   const int sky_from_tile = sky_b.first + sky_b.count;
   const VertexSource source = {nullptr, c->d_vsoa, c->d_inst_model, c->d_inst_normal};
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
-  launch_setup_and_bin(s, dp, source, c->d_indices, c->d_setup, c->d_records, (uint32_t)c->setup_cap, c->d_tile_count, c->d_bins, c->d_overflow,
-                       (uint32_t)c->overflow_cap, counters, c->n_indices / 3, c->n_instances, sky_b);
+  launch_setup_and_bin(s, dp, source, c->d_indices, fw.setup, fw.records, (uint32_t)fw.setup_cap, fw.tile_count, fw.bins, fw.overflow,
+                       (uint32_t)fw.overflow_cap, counters, c->n_indices / 3, c->n_instances, sky_b);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
   // the visibility buffer is only written when someone will read it: the caller (vis output) or the
   // coverage count of the statistics
   const bool write_vis = d_vis != nullptr || want_host_vis || timed;
   if (msaa)
-    launch_raster_msaa(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
+    launch_raster_msaa(s, dp, fw.setup, fw.tile_count, fw.bins, fw.overflow, (uint32_t)fw.overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
                        counters, next_counters, c->d_tile_live, write_vis || c->capture_depth, tiles_x, tiles_y);
   else
-    launch_raster(s, dp, c->d_setup, c->d_tile_count, c->d_bins, c->d_overflow, (uint32_t)c->overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
-                  counters, next_counters, c->quad_lists, write_vis, pr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
+    launch_raster(s, dp, fw.setup, fw.tile_count, fw.bins, fw.overflow, (uint32_t)fw.overflow_cap, vis, (c->capture_depth && !static_memory) ? c->d_depth : nullptr,
+                  counters, next_counters, fw.lists, write_vis, pr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
 
   ResolveInputs in;
-  in.records = c->d_records; in.vout = c->d_vout; in.indices = c->d_indices;
+  in.records = fw.records; in.vout = c->d_vout; in.indices = c->d_indices;
   for (int i = 0; i < 5; ++i) in.tex[i] = c->tex[i];
   in.irr = c->irr; in.pre = c->pre; in.sky = c->sky;
   in.irr_b = pr->irr_b.cube; in.pre_b = pr->pre_b.cube; in.sky_b = pr->sky_b.cube;
   in.lut = c->d_lut; in.lut_pair = pr->d_lut_pair; in.lut_size = c->lut_size;
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
   if (msaa) launch_surface_msaa(s, dp, in, pr->d_srgb_lut, vis, c->d_tile_live, color, W, rows, fast);
-  else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, c->quad_lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
+  else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, fw.lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
@@ -445,6 +522,12 @@ int pbr_create(int device_ordinal, PbrContext** ctx_out) {
     pbr_destroy(c);
     return rc;
   };
+  if (device_ordinal < kMaxDevices && !g_scratch_ptr[device_ordinal]) {
+    // once per device, with that device current: where this GPU keeps its copy of the fixed working memory
+    void* p = nullptr;
+    if ((e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch))) != hipSuccess) return bail("hipGetSymbolAddress(scratch)", e);
+    g_scratch_ptr[device_ordinal] = static_cast<unsigned char*>(p);
+  }
   if ((e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) return bail("hipStreamCreate", e);
   c->stream = c->own_stream;
   {
@@ -506,6 +589,11 @@ int pbr_synchronize(PbrContext* c) {
   DeviceGuard guard(c->device);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  if (priv_of(c)->used_static && c->device < kMaxDevices && g_scratch_ptr[c->device]) {
+    uint32_t flag = 0;   // the capacity flag of the last pbr_draw_frame_static on this device
+    HIP_TRY(c, hipMemcpy(&flag, g_scratch_ptr[c->device] + static_layout::kCounters + 2 * sizeof(uint32_t), sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) return fail(c, PBR_E_STATE, flag == 1 ? "triangle setup buffer overflow" : "tile bin overflow list full");
+  }
   return check_sticky(c);
 }
 
@@ -847,6 +935,12 @@ int pbr_draw_frame_device(PbrContext* c, const PbrFrameUniforms* u, int32_t w, i
   if (!c) return PBR_E_ARG;
   if (!d_rgba8) return fail(c, PBR_E_ARG, "colour output pointer is null");
   return draw_common(c, u, w, h, y0, y1, d_rgba8, d_vis, false, stats);
+}
+
+int pbr_draw_frame_static(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1, void* d_rgba8) {
+  if (!c) return PBR_E_ARG;
+  if (!d_rgba8) return fail(c, PBR_E_ARG, "colour output pointer is null");
+  return draw_common(c, u, w, h, y0, y1, d_rgba8, nullptr, false, nullptr, true);
 }
 
 int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1, uint8_t* rgba8_out, uint32_t* vis_out,
