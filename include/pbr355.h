@@ -141,8 +141,9 @@ int pbr_ibl_prefilter_shard_range(PbrContext* ctx, int32_t shard_index, int32_t 
  * order and cuts[shard_count] the texel count of the whole map (shard_count + 1 entries).  A texel of level m
  * weighs the number of the 1024 GGX samples that contribute at that level's roughness (those with N.L > 0,
  * prefiltermap.wgsl:138; roughness 0 needs a single one) plus a small constant for the per-texel work, so level 0,
- * three quarters of the texels and almost none of the work, does not fill most shards.  Host arithmetic only:
- * needs neither a context nor a device. */
+ * three quarters of the texels and almost none of the work, does not fill most shards; a sample of the +-Y faces and
+ * of the rougher levels weighs more by factors measured on MI355X (its source pixels are scattered over more cache
+ * lines).  Host arithmetic only: needs neither a context nor a device. */
 int pbr_ibl_prefilter_partition(int32_t size, int32_t mips, int32_t shard_count, uint64_t* cuts);
 /* Number of the 1024 samples of prefiltermap.wgsl:131-168 that contribute (N.L > 0) at level `level` of `mips`
  * levels: the executed work per texel, for cost models and benchmarks.  Host arithmetic only. */

@@ -6,6 +6,7 @@
 // cross-lane shuffles, and texel gathers are 16-byte loads.
 #include "pbr_internal.h"
 #include "devmath.h"
+#include "equirect_math.h"
 
 namespace {
 
@@ -194,10 +195,19 @@ __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const P
   for (int i = sub; i < n_samples; i += SPLIT) {
     const PrefilterSample s = samples[i];
     const V3 L = sample_to_world(T, B, N, s.lx, s.ly, s.lz);
-    const float u = atan2f(L.z, L.x) * INV_ATAN_X + 0.5f;
-    const float v = asinf(fminf(fmaxf(L.y, -1.0f), 1.0f)) * INV_ATAN_Y + 0.5f;
     const int w0 = max(1, hdr.w >> s.l0), h0 = max(1, hdr.h >> s.l0), w1 = max(1, hdr.w >> s.l1), h1 = max(1, hdr.h >> s.l1);
-    const int x0 = max(min((int)(u * (float)w0), w0 - 1), 0), y0 = max(min((int)(v * (float)h0), h0 - 1), 0);
+    float tu = 0.0f, tv = 0.0f, u = 0.0f, v = 0.0f;   // u, v: set (and used) on the library path only
+    bool decided = false;
+    // Only the pixel matters: polynomials decide it unless a coordinate is within their error of a pixel boundary in
+    // some lane (about one wavefront-sample in eight at the finest source level used); then the library functions
+    // the shader's atan2 / asin stand for are evaluated, so the pixel is theirs in every case.
+    if constexpr (POW2) decided = equirect_pixel_fast(L.x, L.y, L.z, (float)w0, (float)h0, tu, tv);
+    if (__builtin_amdgcn_ballot_w64(!decided) != 0ull) {
+      u = atan2f(L.z, L.x) * INV_ATAN_X + 0.5f;
+      v = asinf(fminf(fmaxf(L.y, -1.0f), 1.0f)) * INV_ATAN_Y + 0.5f;
+      tu = u * (float)w0; tv = v * (float)h0;
+    }
+    const int x0 = max(min((int)tu, w0 - 1), 0), y0 = max(min((int)tv, h0 - 1), 0);
     int x1, y1;
     uint32_t row0, row1;
     if constexpr (POW2) {
@@ -207,7 +217,7 @@ __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const P
       x1 = x0 >> (s.l1 - s.l0); y1 = y0 >> (s.l1 - s.l0);
       row0 = (uint32_t)y0 << (log2w - s.l0); row1 = (uint32_t)y1 << (log2w - s.l1);
     } else {
-      x1 = max(min((int)(u * (float)w1), w1 - 1), 0); y1 = max(min((int)(v * (float)h1), h1 - 1), 0);
+      x1 = max(min((int)(u * (float)w1), w1 - 1), 0); y1 = max(min((int)(v * (float)h1), h1 - 1), 0);   // not POW2: always the library path
       row0 = (uint32_t)y0 * (uint32_t)w0; row1 = (uint32_t)y1 * (uint32_t)w1;
     }
     const float4 a = hdr.base[hdr.off[s.l0] + row0 + (uint32_t)x0];

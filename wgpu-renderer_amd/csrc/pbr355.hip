@@ -171,16 +171,28 @@ int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out,
 // renderer.ts:1559: roughness = mip / (maxMipLevels - 1) stored as f32; a single level gets 0
 float prefilter_roughness(int level, int mips) { return mips > 1 ? (float)((double)level / (double)(mips - 1)) : 0.0f; }
 
-// Cost of one output texel of each level, in units of one kept sample: the samples the level's table keeps plus
-// a constant for the work a texel does whatever its sample count (direction, tangent frame, the 16-byte store).
+// Cost model of the prefilter, for cutting it into shards of equal duration.  A texel of level m costs the samples
+// the level's table keeps (those with N.L > 0; one at roughness 0) plus a constant for the work a texel does whatever
+// its sample count (direction, tangent frame, the 16-byte store) - times what a sample costs there, which is the
+// price of its two source-pixel gathers and was measured on MI355X (2048^2 x 10 levels from a 4096 x 2048 source,
+// every face of every level filtered on its own, scripts/gpu_prefilter_shards.py):
+//   * the +-Y faces look at the pole rows of the equirect image, where a block of neighbouring directions is
+//     stretched over many more pixels of a row (more cache lines per wavefront load): 1.44 x the other faces at
+//     the smoothest filtered level, whose samples read the finest source levels, 1.1 x and less at rougher ones;
+//   * rougher levels scatter their samples wider and are smaller launches: 1.27 x and 1.37 x per sample.
+// Only the balance of the shards depends on these numbers, never a result.
 constexpr uint64_t PREFILTER_TEXEL_OVERHEAD = 8;
-void prefilter_level_costs(int mips, int* kept, uint64_t* cost) {
+struct PrefilterCost { int kept[PBR_MAX_LEVELS]; uint64_t per_texel[PBR_MAX_LEVELS][6]; };
+void prefilter_costs(int mips, PrefilterCost* pc) {
   std::vector<PrefilterSample> table(PBR_PREFILTER_SAMPLES);
   for (int m = 0; m < mips; ++m) {
     float weight;
-    const int n = build_prefilter_table(prefilter_roughness(m, mips), PBR_MAX_LEVELS, table.data(), &weight);   // the count does not depend on the source's level count
-    if (kept) kept[m] = n;
-    if (cost) cost[m] = (uint64_t)n + PREFILTER_TEXEL_OVERHEAD;
+    const float roughness = prefilter_roughness(m, mips);
+    const int n = build_prefilter_table(roughness, PBR_MAX_LEVELS, table.data(), &weight);   // the count does not depend on the source's level count
+    pc->kept[m] = n;
+    const uint64_t side = roughness == 0.0f ? 100 : roughness <= 0.17f ? 100 : roughness <= 0.28f ? 127 : 137;   // per sample, in hundredths
+    const uint64_t pole = roughness == 0.0f ? 100 : roughness <= 0.17f ? 144 : roughness <= 0.28f ? 141 : 144;
+    for (int f = 0; f < 6; ++f) pc->per_texel[m][f] = ((uint64_t)n + PREFILTER_TEXEL_OVERHEAD) * ((f == 2 || f == 3) ? pole : side);
   }
 }
 
@@ -188,21 +200,28 @@ void prefilter_level_costs(int mips, int* kept, uint64_t* cost) {
 // The reference filters level after level (renderer.ts:1558-1609); level 0 holds three quarters of the texels
 // but, at roughness 0, almost none of the work, so equal texel counts would leave most shards idle.
 void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
-  uint64_t cost[PBR_MAX_LEVELS], texels[PBR_MAX_LEVELS], total_cost = 0, total_texels = 0;
-  prefilter_level_costs(mips, nullptr, cost);
+  PrefilterCost pc;
+  prefilter_costs(mips, &pc);
+  uint64_t total_cost = 0, total_texels = 0;
   for (int m = 0; m < mips; ++m) {
     const uint64_t s = (uint64_t)std::max(1, size >> m);
-    texels[m] = 6 * s * s;
-    total_cost += texels[m] * cost[m];
-    total_texels += texels[m];
+    for (int f = 0; f < 6; ++f) total_cost += s * s * pc.per_texel[m][f];
+    total_texels += 6 * s * s;
   }
   cuts[0] = 0; cuts[n] = total_texels;
   for (int k = 1; k < n; ++k) {
     const uint64_t target = (uint64_t)(((unsigned __int128)total_cost * (unsigned)k) / (unsigned)n);
     uint64_t before_cost = 0, before_texels = 0;
-    int m = 0;
-    while (m < mips - 1 && before_cost + texels[m] * cost[m] <= target) { before_cost += texels[m] * cost[m]; before_texels += texels[m]; ++m; }
-    cuts[k] = before_texels + std::min(texels[m], (target - before_cost) / cost[m]);
+    bool placed = false;
+    for (int m = 0; m < mips && !placed; ++m) {
+      const uint64_t s = (uint64_t)std::max(1, size >> m), face_texels = s * s;
+      for (int f = 0; f < 6 && !placed; ++f) {
+        const uint64_t c = face_texels * pc.per_texel[m][f];
+        if (before_cost + c > target) { cuts[k] = before_texels + (target - before_cost) / pc.per_texel[m][f]; placed = true; }
+        else { before_cost += c; before_texels += face_texels; }
+      }
+    }
+    if (!placed) cuts[k] = total_texels;
   }
 }
 
@@ -771,9 +790,9 @@ int pbr_ibl_prefilter_partition(int32_t size, int32_t mips, int32_t shard_count,
 int pbr_ibl_prefilter_kept_samples(int32_t mips, int32_t level, int32_t* kept) {
   if (!kept) return fail(nullptr, PBR_E_ARG, "kept is null");
   if (mips < 1 || mips > PBR_MAX_LEVELS || level < 0 || level >= mips) return fail(nullptr, PBR_E_ARG, "bad level %d of %d", level, mips);
-  int counts[PBR_MAX_LEVELS];
-  prefilter_level_costs(mips, counts, nullptr);
-  *kept = counts[level];
+  PrefilterCost pc;
+  prefilter_costs(mips, &pc);
+  *kept = pc.kept[level];
   return PBR_OK;
 }
 
