@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the PBR frame path on MI355X.
 
-A step is one 3840x2160 DamagedHelmet PBR+IBL frame (vertex transform, binning, tile raster + skybox,
-surface shading) rendered into device memory with every input already resident in HBM.  With
---gpus N > 1 the frames of a camera orbit (one `updateCameraRotation(-10, 0)` step per frame) are
-dealt round-robin to the ranks, one process per GPU, no data-path collective: weak scaling.  Each
-rank keeps --in-flight frames in flight (default 3): that many renderer contexts, each on its own
-stream with its own colour target, take the rank's frames in turn, so the short latency-bound
-geometry kernels of one frame overlap the shading of the previous one.
+Default mode (`--mode orbit`): a step is one 3840x2160 DamagedHelmet PBR+IBL frame (vertex transform, binning, tile
+raster + skybox, surface shading) rendered into device memory with every input already resident in HBM.  With
+--gpus N > 1 the frames of a camera orbit (one `updateCameraRotation(-10, 0)` step per frame) are dealt round-robin
+to the ranks, one process per GPU, no data-path collective: weak scaling.  Each rank keeps --in-flight frames in
+flight (default 3): one renderer context plus forks of it, which share ONE copy of the scene on the device and each
+own a stream and a colour target, take the rank's frames in turn, so the short latency-bound geometry kernels of
+one frame overlap the shading of the previous one.  `config.single_frame_ms` is the same frame with nothing else in
+flight.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the surface-shading kernel, timed with HIP events
-on the stream it runs on over the timed region (where it shares the chip with the other frames in
-flight); `roofline.isolated` is the same kernel on the same frames with nothing else running.
-`cpu_baseline` is the CPU oracle (a restatement of the reference WGSL, not Dawn/SwiftShader)
-rendering frames of the same orbit on the host cores.
+`--mode strips`: the synthetic stress scene (10 x 10 instanced helmets, 7680x4320).  Every rank renders its
+even-aligned band of rows of every frame and the bands are gathered to rank 0 over RCCL: strong scaling of one frame.
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).
+
+Prints ONE JSON line on rank 0.  `roofline` is for the surface-shading kernel: its launch duration measured with
+HIP events on the stream it runs on, with the chip to itself (`roofline.in_flight` has the same kernel inside the
+timed region, where the other frames' kernels stretch it).  `cpu_baseline` is the CPU oracle (a restatement of the
+reference WGSL, not Dawn/SwiftShader) rendering frames of the same orbit on the host cores.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +35,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_traffic.json")   # PMC pass of scripts/gpu_traffic.sh over this same workload
+
+
+def _newest(*names):
+    for n in names:
+        p = os.path.join(ROOT, "profiles", n)
+        if os.path.isfile(p):
+            return p
+    return os.path.join(ROOT, "profiles", names[-1])
+
+
+TRAFFIC_FILE = _newest("r02_traffic.json", "r01_traffic.json")   # PMC pass of scripts/gpu_traffic.sh over this same workload
+VALU_FILE = _newest("r02_valu.json", "r01_valu.json")            # SQ_INSTS_VALU per launch, from scripts/gpu_pmc_frame.sh
+FRAME_KERNELS = ["setup_kernel", "raster_kernel", "resolve_surface_fast_kernel"]
+SIMDS, PEAK_CLOCK_HZ, CYCLES_PER_VALU_INSTRUCTION = 1024, 2.4e9, 4.0   # one vector instruction per SIMD every four cycles (measured)
 
 
 def measured_traffic(kernel):
@@ -41,8 +61,9 @@ def measured_traffic(kernel):
         return None
 
 
-VALU_FILE = os.path.join(ROOT, "profiles", "r01_valu.json")   # SQ_INSTS_VALU per launch, from scripts/gpu_pmc_frame.sh
-SIMDS, PEAK_CLOCK_HZ, CYCLES_PER_VALU_INSTRUCTION = 1024, 2.4e9, 4.0   # one vector instruction per SIMD every four cycles (measured)
+def measured_frame_traffic():
+    parts = [measured_traffic(k) for k in FRAME_KERNELS]
+    return None if any(p is None for p in parts) else float(sum(parts))
 
 
 def valu_issue(kernels, ms):
@@ -58,21 +79,59 @@ def valu_issue(kernels, ms):
     return {"wave_instructions": n, "frac": n * CYCLES_PER_VALU_INSTRUCTION / (SIMDS * ms * 1e-3 * PEAK_CLOCK_HZ)}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=360, help="frames per rank in the timed region (360 = one full orbit on one GPU)")
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--steps", type=int, default=None, help="steps per rank in the timed region (default: 360 frames = one orbit; 20 in strips mode)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", choices=("orbit", "strips"), default="orbit")
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--skybox-size", type=int, default=1024)
     ap.add_argument("--in-flight", type=int, default=3,
-                    help="frames in flight per GPU: that many renderer contexts, each on its own stream, take the rank's frames in turn")
+                    help="frames in flight per GPU: one renderer context plus forks of it, each on its own stream, take the rank's frames in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the IBL prefilter timing (2048^2, 10 mips)")
     ap.add_argument("--prefilter-size", type=int, default=2048)
     ap.add_argument("--prefilter-mips", type=int, default=10)
-    return ap.parse_args()
+    args = ap.parse_args(argv)
+    strips = args.mode == "strips"
+    if args.steps is None:
+        args.steps = 20 if strips else 360
+    if args.warmup is None:
+        args.warmup = 3 if strips else 20
+    if args.width is None:
+        args.width = 7680 if strips else 3840
+    if args.height is None:
+        args.height = 4320 if strips else 2160
+    return args
+
+
+def launch_plan(args, env):
+    """What this invocation has to do about ranks: ("run", world) when it is one rank of `world` (or the only one),
+    ("spawn", n) when it was asked for n GPUs outside a launcher and has to start the ranks itself, ("error", text)
+    when the launcher's world size contradicts --gpus."""
+    world = env.get("WORLD_SIZE")
+    if world is None:
+        return ("spawn", args.gpus) if args.gpus > 1 else ("run", 1)
+    world = int(world)
+    if world != args.gpus:
+        return ("error", f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    return ("run", world)
+
+
+def spawn_ranks(n, argv):
+    """Starts the n ranks with torch.distributed.run on this node and relays rank 0's JSON line."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    if proc.returncode != 0 or not lines:
+        sys.stdout.write(proc.stdout)
+        raise SystemExit(proc.returncode or 1)
+    print(lines[-1], flush=True)
+    raise SystemExit(0)
 
 
 def cpu_baseline(pkg, renderer, W, H, budget_s=12.0):
@@ -108,16 +167,18 @@ def cpu_baseline(pkg, renderer, W, H, budget_s=12.0):
                       f"OpenMP {threads} threads; IBL maps taken as inputs"}
 
 
-def main():
-    args = parse_args()
-    import torch
-    import torch.distributed as dist
+def stress_instances(pkg, base_model):
+    """The synthetic stress layout: a 10 x 10 grid of helmets 2.5 units apart in x and y."""
+    mx = pkg.mathx
+    return np.stack([mx.mul(mx.translate(mx.identity(), [(i - 4.5) * 2.5, (j - 4.5) * 2.5, 0.0]), base_model) for j in range(10) for i in range(10)])
 
+
+def init_distributed(args, torch, dist):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # PBR_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, barriers, reductions, the prefilter's
-    # all-gather) with a single rank, to rehearse it on a one-GPU box under torch.distributed.run
+    # PBR_BENCH_FORCE_DIST=1 takes the multi-rank code path (process group, barriers, reductions, the exchanges) with a
+    # single rank, to rehearse it on a one-GPU box under torch.distributed.run
     use_dist = world > 1 or bool(os.environ.get("PBR_BENCH_FORCE_DIST"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
@@ -134,20 +195,46 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+    return world, rank, local_rank, use_dist, dev, frame_streams
 
-    import __graft_entry__ as entry
-    pkg = entry.load_package()
+
+def timed_region(torch, dist, use_dist, dev, steps, step_fn):
+    """EXACTLY `steps` steps between a barrier + synchronize on both sides; returns the max over ranks, in seconds."""
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(i)
+    torch.cuda.synchronize(dev)
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    return elapsed
+
+
+def check_lanes(lanes):
+    """Frames drawn without statistics report a capacity overflow (set-up buffer, tile bins) only when the context is
+    synchronised through the library: do that for every context, so that a wrong frame cannot pass as a number."""
+    for rr, _, _ in lanes:
+        rr.synchronize()
+
+
+def run_orbit(args, pkg, torch, dist, ctxinfo):
+    world, rank, local_rank, use_dist, dev, frame_streams = ctxinfo
     W, H = args.width, args.height
     K = max(1, args.in_flight)
-    lib = None
-    lanes = []                                # one renderer context + stream + colour target per frame in flight
-    for _ in range(K):
-        r = pkg.Renderer(width=W, height=H, device=local_rank, skybox_size=args.skybox_size)
-        r.init()
-        stream = frame_streams[len(lanes)]    # a real (non-null) stream, so torch events and syncs see the kernels
-        r.set_stream(stream.cuda_stream)
-        lanes.append((r, stream, torch.empty((H, W, 4), dtype=torch.uint8, device=dev)))
-    r = lanes[0][0]
+    r = pkg.Renderer(width=W, height=H, device=local_rank, skybox_size=args.skybox_size)
+    r.init()
+    lanes = []                                # one context (the first owns the scene, the others are forks of it) + stream + colour target per frame in flight
+    for k in range(K):
+        rr = r if k == 0 else r.fork()
+        rr.set_stream(frame_streams[k].cuda_stream)   # a real (non-null) stream, so torch events and syncs see the kernels
+        lanes.append((rr, frame_streams[k], torch.empty((H, W, 4), dtype=torch.uint8, device=dev)))
     lib = r._lib
     torch.cuda.set_stream(lanes[0][1])
 
@@ -170,33 +257,22 @@ def main():
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize(dev)
-    # the dominant kernel is timed on the first context's stream, on the first quarter (at least eight) of
-    # the frames that context renders in the timed region: an event pair costs about 10 us of stream time
+    # the dominant kernel inside the timed region: timed on the first context's stream, on the first quarter (at least
+    # eight) of the frames that context renders: an event pair costs about 10 us of stream time
     pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, max(8, (args.steps + K - 1) // K // 4)))
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        step(i)
-    torch.cuda.synchronize(dev)
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_region(torch, dist, use_dist, dev, args.steps, lambda i: step(args.warmup + i))
     frames, surf_total, span = C.c_int32(), C.c_float(), C.c_float()
     pkg._lib.check(r._ctx, lib.pbr_profile_end(r._ctx, C.byref(frames), C.byref(surf_total), C.byref(span)))
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    check_lanes(lanes)
 
-    # the dominant kernel once more with the chip to itself: same frames, first context only
+    # the dominant kernel with the chip to itself, and the frame with nothing else in flight: same frames, first context only
     iso_frames, iso_total, iso_span = C.c_int32(), C.c_float(), C.c_float()
     n_iso = min(args.steps, 20)
     pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, n_iso))
     for i in range(args.warmup, args.warmup + n_iso):
         r.draw_frame_device(lanes[0][2].data_ptr(), uniforms=uniforms[i])
     pkg._lib.check(r._ctx, lib.pbr_profile_end(r._ctx, C.byref(iso_frames), C.byref(iso_total), C.byref(iso_span)))
+    r.synchronize()
 
     # coverage for the bandwidth model: sampled on a second pass over a tenth of the timed views (a
     # statistics call synchronises, so it stays out of the timed region)
@@ -222,10 +298,14 @@ def main():
         # texels per covered pixel and one rgba32f skybox texel per background pixel.
         surf_bytes = c * npix * 28.0
         frame_bytes = n_verts * 32 + n_idx * 2 + npix * 12.0 + c * npix * 20.0 + (1.0 - c) * npix * 16.0
-        surf_gbs = surf_bytes / (surf_ms * 1e-3) / 1e9
+        in_flight_gbs = surf_bytes / (surf_ms * 1e-3) / 1e9
         iso_ms = iso_total.value / max(iso_frames.value, 1)
         iso_gbs = surf_bytes / (iso_ms * 1e-3) / 1e9
+        single_frame_ms = iso_span.value / max(iso_frames.value - 1, 1)
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
+        frame_traffic = measured_frame_traffic()
+        issue_one = valu_issue(["resolve_surface_fast_kernel"], iso_ms)
+        issue_frame = valu_issue(FRAME_KERNELS, frame_ms)
         result = {
             "metric": "shaded Mpix/s (DamagedHelmet 4K PBR+IBL)",
             "value": world * args.steps * npix / 1e6 / elapsed,
@@ -241,66 +321,163 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"DamagedHelmet {W}x{H} single frame, {args.skybox_size}^2 skybox cube, irradiance 32^2, prefilter 128^2 x5, LUT 512^2, synthetic 4096x2048 HDR"
                                    + f"; step i renders frame i of a 1-degree-per-frame camera orbit that starts at the reference's default view, frame f on rank f mod {world}",
-                       "covered_fraction": c, "triangles": tri_sum // max(n_cov, 1), "parallelism": "replicas only" if world == 1 else f"frame-sharded x{world}", "frames_in_flight_per_gpu": K},
-            "kernel_ms": {"resolve_surface_fast_kernel": surf_ms, "one_context_frame_to_frame": span.value / max(nf - 1, 1)},
-            "roofline": {"bound": "hbm", "kernel": "resolve_surface_fast_kernel", "achieved": surf_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": surf_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("resolve_surface_fast_kernel"), "algorithmic_bytes": surf_bytes,
-                         "isolated": {"ms": iso_ms, "achieved": iso_gbs, "frac": iso_gbs / HBM_PEAK_GBS,
-                                      "frame_ms": iso_span.value / max(iso_frames.value - 1, 1),
-                                      "valu_issue": valu_issue(["resolve_surface_fast_kernel"], iso_ms)}},
-            "frame_roofline": {"bound": "hbm", "kernels": "all kernels of one frame (vertex, setup, raster+sky, surface); wall time per frame with the configured frames in flight", "achieved": frame_gbs,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS, "algorithmic_bytes": frame_bytes,
-                               "valu_issue": valu_issue(["setup_kernel", "raster_kernel", "resolve_surface_fast_kernel"], frame_ms)},
+                       "covered_fraction": c, "triangles": tri_sum // max(n_cov, 1), "parallelism": "replicas only" if world == 1 else f"frame-sharded x{world}",
+                       "frames_in_flight_per_gpu": K, "single_frame_ms": single_frame_ms,
+                       "single_frame_mpix_per_s": npix / 1e6 / (single_frame_ms * 1e-3),
+                       "covered_mpix_per_s_of_surface_kernel": c * npix / 1e6 / (iso_ms * 1e-3)},
+            "kernel_ms": {"resolve_surface_fast_kernel": iso_ms, "resolve_surface_fast_kernel_in_flight": surf_ms,
+                          "one_context_frame_to_frame": span.value / max(nf - 1, 1)},
+            # the launch duration is the kernel's alone (nothing else on the chip); inside the timed region the same
+            # kernel shares the chip with the other frames' kernels and its event-to-event time is longer than a step
+            "roofline": {"bound": "hbm", "kernel": "resolve_surface_fast_kernel", "launch_ms": iso_ms, "achieved": iso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": iso_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("resolve_surface_fast_kernel"), "algorithmic_bytes": surf_bytes,
+                         "bound_measured": "valu_issue", "valu_issue": issue_one,
+                         "in_flight": {"ms": surf_ms, "achieved": in_flight_gbs, "frac": in_flight_gbs / HBM_PEAK_GBS,
+                                       "note": "event-to-event time of the kernel inside the timed region, stretched by the other frames in flight"}},
+            "frame_roofline": {"bound": "hbm", "kernels": "all kernels of one frame (setup + sky, raster + sky, surface); wall time per frame with the configured frames in flight",
+                               "achieved": frame_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS, "algorithmic_bytes": frame_bytes,
+                               "traffic": frame_traffic,
+                               "traffic_frac": None if frame_traffic is None else frame_traffic / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "note": "algorithmic_bytes is the nominal figure of the survey's model: it counts 8 B per pixel of visibility-buffer write + read that the "
+                                       "timed path does not perform (the resolve works from quad lists) and one rgba32f texel per sky pixel that a magnified cube never "
+                                       "fetches; traffic is what the L2s' memory-side counters measured per frame",
+                               "bound_measured": "valu_issue", "valu_issue": issue_frame},
         }
+    return r, lanes, result
 
-    if not args.no_prefilter:
-        # second headline figure: the IBL GGX prefilter at 2048^2 x 10 mips x 1024 samples.  One GPU filters
-        # the whole map; with several ranks each filters its texel range and one all-gather (RCCL) makes
-        # the map whole on every GPU.
-        texels = sum(6 * max(1, args.prefilter_size >> m) ** 2 for m in range(args.prefilter_mips))
-        info = {"config": f"{args.prefilter_size}^2 cube, {args.prefilter_mips} mips, 1024 samples/texel", "n_gpus": world}
-        try:
-            import importlib
-            parallel = importlib.import_module(pkg.__name__ + ".parallel")
 
-            def run_prefilter():
-                if not use_dist:
-                    pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, args.prefilter_size, args.prefilter_mips, 1024, 0, 1))
-                else:
-                    parallel.prefilter_sharded(r, args.prefilter_size, args.prefilter_mips, rank, world, dev)
-                torch.cuda.synchronize(dev)
-            run_prefilter()                                   # allocate + warm
-            if use_dist:
-                dist.barrier()
-            t0 = time.perf_counter()
-            run_prefilter()
-            if use_dist:
-                dist.barrier()
-            ms = (time.perf_counter() - t0) * 1e3
-            if use_dist:
-                tmax = torch.tensor([ms], dtype=torch.float64, device=dev)
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                ms = float(tmax.item())
-                info["exchange"] = f"all-gather of the {texels * 16 / 1e6:.0f} MB map included"
-            info.update({"ms": ms, "algorithmic_tflops": texels * 1024 * 110 / (ms * 1e-3) / 1e12, "fp32_peak_tflops": 157.3 * world})
-        except Exception as exc:                             # the frame benchmark above stands on its own
-            info["error"] = f"{type(exc).__name__}: {exc}"
-        if rank == 0:
-            result["ibl_prefilter"] = info
-        # restore the frame's prefilter map
-        pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, r.prefilter_size, r.prefilter_mips, 1024, 0, 1))
+def run_strips(args, pkg, torch, dist, ctxinfo):
+    """The stress scene across ranks: every rank uploads the whole instanced scene, draws rows strip_rows(H, rank, world)
+    of every frame and sends them to rank 0 (RCCL gather); a step is one whole frame put together on rank 0."""
+    world, rank, local_rank, use_dist, dev, frame_streams = ctxinfo
+    import importlib
+    parallel = importlib.import_module(pkg.__name__ + ".parallel")
+    sharding = importlib.import_module(pkg.__name__ + ".sharding")
+    W, H = args.width, args.height
+    loader = pkg.glTFLoader(); loader.load(pkg.renderer.DEFAULT_MODEL)
+    models = stress_instances(pkg, np.asarray(loader.get_geometries()[0].model, dtype=np.float32))
+    r = pkg.Renderer(width=W, height=H, device=local_rank, skybox_size=args.skybox_size, instance_models=models)
+    r.init()
+    r.camera.update_camera_distance((5.0 - 30.0) * 100.0, 0.0)     # dolly out to 30 units: all hundred helmets in view
+    stream = frame_streams[0]
+    r.set_stream(stream.cuda_stream)
+    torch.cuda.set_stream(stream)
+    y0, y1 = sharding.strip_rows(H, rank, world)
+    strip = torch.empty((y1 - y0, W, 4), dtype=torch.uint8, device=dev)
+    n_local = args.warmup + args.steps
+    uniforms = []
+    for _ in range(n_local):
+        uniforms.append(r.frame_uniforms())
+        r.camera.update_camera_rotation(-10.0, 0.0)
+    t_render, t_gather = [0.0], [0.0]
+    frame_box = [None]
+
+    def step(i, timed=True):
+        a = time.perf_counter()
+        r.draw_frame_device(strip.data_ptr(), y0=y0, y1=y1, uniforms=uniforms[i])
+        stream.synchronize()
+        b = time.perf_counter()
+        frame_box[0] = parallel.gather_strips(strip, H, W, rank, world, dst=0) if use_dist else strip
         torch.cuda.synchronize(dev)
+        if timed:
+            t_render[0] += b - a
+            t_gather[0] += time.perf_counter() - b
 
-    if rank == 0 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(pkg, r, W, H)
+    for i in range(args.warmup):
+        step(i, timed=False)
+    elapsed = timed_region(torch, dist, use_dist, dev, args.steps, lambda i: step(args.warmup + i))
+    r.synchronize()
+    stats = pkg._lib.FrameStats()
+    r.draw_frame_device(strip.data_ptr(), y0=y0, y1=y1, uniforms=uniforms[args.warmup], stats=stats)
+    result = None
+    if rank == 0:
+        npix = W * H
+        frame_ms = elapsed / args.steps * 1e3
+        result = {
+            "metric": "shaded Mpix/s (100x instanced DamagedHelmet 7680x4320, screen strips)",
+            "value": args.steps * npix / 1e6 / elapsed, "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": frame_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic stress: 10x10 instanced DamagedHelmet ({models.shape[0] * r.geometries[0].indices.size // 3} triangles) at {W}x{H}, "
+                                   f"{world} even-aligned row strips, one per rank, gathered to rank 0", "parallelism": f"screen strips x{world}",
+                       "rank0_rows": [y0, y1], "rank0_setup_triangles": int(stats.setup_triangles), "rank0_covered_fraction_of_strip": stats.covered_pixels / float((y1 - y0) * W)},
+            "render_ms_rank0": t_render[0] / args.steps * 1e3, "gather_ms_rank0": t_gather[0] / args.steps * 1e3,
+            "exchange": "none (one rank)" if not use_dist else f"gather of {world} rgba8 bands ({npix * 4 / 1e6:.0f} MB per frame) to rank 0 over RCCL",
+        }
+    return r, [(r, stream, strip)], result
+
+
+def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
+    """Second headline figure: the IBL GGX prefilter at 2048^2 x 10 mips x 1024 samples.  One GPU filters the whole map;
+    with several ranks each filters its shard (equal cost, not equal texel counts) and one all-gather (RCCL) makes the
+    map whole on every GPU."""
+    world, rank, local_rank, use_dist, dev, _ = ctxinfo
+    import importlib
+    parallel = importlib.import_module(pkg.__name__ + ".parallel")
+    sharding = importlib.import_module(pkg.__name__ + ".sharding")
+    lib = r._lib
+    size, mips = args.prefilter_size, args.prefilter_mips
+    level_texels = [6 * max(1, size >> m) ** 2 for m in range(mips)]
+    texels = sum(level_texels)
+    info = {"config": f"{size}^2 cube, {mips} mips, 1024 samples/texel", "n_gpus": world}
+    try:
+        def once():
+            if not use_dist:
+                pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, size, mips, 1024, 0, 1))
+            else:
+                parallel.prefilter_sharded(r, size, mips, rank, world, dev)
+            torch.cuda.synchronize(dev)
+        once()                                   # allocate + warm
+        ms = timed_region(torch, dist, use_dist, dev, 1, lambda i: once()) * 1e3
+        if use_dist:
+            info["exchange"] = f"all-gather of the {texels * 16 / 1e6:.0f} MB map included"
+            cuts = sharding.prefilter_cuts(size, mips, world)
+            info["shard_texels"] = [b - a for a, b in zip(cuts, cuts[1:])]
+        kept = sharding.prefilter_kept_samples(mips)
+        executed = sum(k * t for k, t in zip(kept, level_texels))
+        info.update({"ms": ms,
+                     # work in the reference's units: every texel of every level loops over 1024 samples (prefiltermap.wgsl:131)
+                     "reference_samples": texels * 1024, "reference_gsamples_per_s": texels * 1024 / (ms * 1e-3) / 1e9,
+                     # work executed: roughness 0 collapses to one sample per texel and samples with N.L <= 0 contribute nothing
+                     "executed_samples": executed, "executed_gsamples_per_s": executed / (ms * 1e-3) / 1e9, "kept_samples_per_level": kept,
+                     "bound_measured": "texture-address path (two 16-byte gathers per sample); see profiles/r02_prefilter_counters.txt"})
+    except Exception as exc:                             # the frame benchmark above stands on its own
+        info["error"] = f"{type(exc).__name__}: {exc}"
+    if rank == 0 and result is not None:
+        result["ibl_prefilter"] = info
+    # restore the frame's prefilter map
+    pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, r.prefilter_size, r.prefilter_mips, 1024, 0, 1))
+    torch.cuda.synchronize(dev)
+
+
+def main():
+    args = parse_args()
+    plan, what = launch_plan(args, os.environ)
+    if plan == "error":
+        raise SystemExit("bench.py: " + what)
+    if plan == "spawn":
+        spawn_ranks(what, sys.argv[1:])
+    import torch
+    import torch.distributed as dist
+    ctxinfo = init_distributed(args, torch, dist)
+    world, rank, local_rank, use_dist, dev, _ = ctxinfo
+
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    if args.mode == "strips":
+        r, lanes, result = run_strips(args, pkg, torch, dist, ctxinfo)
+    else:
+        r, lanes, result = run_orbit(args, pkg, torch, dist, ctxinfo)
+        if not args.no_prefilter:
+            run_prefilter(args, pkg, torch, dist, ctxinfo, r, result)
+        if rank == 0 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(pkg, r, args.width, args.height)
 
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result), flush=True)
-    for rr, _, _ in lanes:
-        rr.close()
+    r.close()
 
 
 if __name__ == "__main__":

@@ -83,6 +83,13 @@ typedef struct PbrFrameStats {
 /* ---- lifetime: replaces requestAdapter/requestDevice, renderer.ts:144-198 ---- */
 int pbr_create(int device_ordinal, PbrContext** ctx_out);
 int pbr_destroy(PbrContext* ctx);
+/* A second context on the same device that draws the SAME scene: it shares the parent's mesh, textures and IBL maps
+ * (one copy in device memory, so frames in flight meet in the caches) and owns only what a frame in flight needs
+ * for itself: a stream, working buffers, counters.  Several frames in flight = one context plus forks, each on its
+ * own stream (the reference keeps frames in flight through the browser's queue, renderer.ts:2033-2050).  A fork
+ * cannot upload or generate anything (PBR_E_STATE); changes made through the parent are seen by its forks' next
+ * frames, and must not overlap them.  Destroy the forks before the parent. */
+int pbr_fork(PbrContext* parent, PbrContext** ctx_out);
 const char* pbr_last_error(const PbrContext* ctx);   /* ctx may be NULL: error of the last failed pbr_create on this thread */
 /* Run this context's work on an existing HIP stream (hipStream_t); NULL restores the context's own. */
 int pbr_set_stream(PbrContext* ctx, void* hip_stream);

@@ -30,3 +30,52 @@ def test_committed_instruction_counts_are_readable():
     # frac = instructions x 4 cycles / (1024 SIMDs x time x 2.4 GHz)
     assert abs(one["frac"] - one["wave_instructions"] * 4 / (1024 * 0.037e-3 * 2.4e9)) < 1e-9
     assert b.valu_issue(["no_such_kernel"], 0.05) is None
+
+
+def test_gpus_flag_starts_the_ranks_or_refuses_a_mismatch():
+    """`bench.py --gpus 2` outside a launcher must not quietly run one rank and report n_gpus 1."""
+    b = _bench()
+    assert b.launch_plan(b.parse_args([]), {}) == ("run", 1)
+    assert b.launch_plan(b.parse_args(["--gpus", "2"]), {}) == ("spawn", 2)
+    assert b.launch_plan(b.parse_args(["--gpus", "8"]), {"WORLD_SIZE": "8"}) == ("run", 8)
+    assert b.launch_plan(b.parse_args(["--gpus", "1"]), {"WORLD_SIZE": "1"}) == ("run", 1)     # a one-rank rehearsal under the launcher
+    kind, text = b.launch_plan(b.parse_args(["--gpus", "4"]), {"WORLD_SIZE": "2"})
+    assert kind == "error" and "WORLD_SIZE=2" in text
+    kind, _ = b.launch_plan(b.parse_args([]), {"WORLD_SIZE": "2"})
+    assert kind == "error"
+
+
+def test_gpus_flag_without_a_launcher_does_not_report_one_gpu(tmp_path):
+    """End to end on a machine without a GPU: the two ranks are started (and fail for want of a GPU); what must not
+    happen is a successful one-rank run."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("on a GPU box this would run the whole benchmark")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-prefilter", "--no-cpu-baseline"],
+                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert proc.returncode != 0
+    assert '"n_gpus": 1' not in proc.stdout
+    assert "needs a GPU" in proc.stdout
+
+
+def test_modes_and_their_defaults():
+    b = _bench()
+    a = b.parse_args([])
+    assert (a.mode, a.width, a.height, a.steps, a.warmup, a.in_flight) == ("orbit", 3840, 2160, 360, 20, 3)
+    s = b.parse_args(["--mode", "strips"])
+    assert (s.width, s.height, s.steps) == (7680, 4320, 20)
+
+
+def test_result_names_what_was_measured():
+    """The JSON line carries the fields a reader needs to tell the isolated kernel time from the in-flight one, the
+    nominal bytes from the measured traffic, and the single-frame latency from the pipelined rate."""
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"single_frame_ms"', '"bound_measured"', '"launch_ms"', '"in_flight"', '"traffic_frac"', '"executed_samples"', '"reference_samples"',
+                '"cpu_baseline"', '"roofline"', '"frame_roofline"'):
+        assert key in text, key
+    assert "check_lanes(lanes)" in text          # every context is synchronised through the library after the timed region
+    b = _bench()
+    assert b.measured_frame_traffic() is not None and b.measured_frame_traffic() > b.measured_traffic("resolve_surface_fast_kernel")

@@ -517,6 +517,56 @@ def test_prefilter_bits_are_those_of_the_first_build():
         r.close()
 
 
+def test_forked_contexts_draw_the_parents_scene(small):
+    """Frames in flight share one copy of the scene: a fork renders the parent's frame bit for bit, on its own stream,
+    interleaved with it; it cannot change the scene, and the parent cannot go away under it."""
+    import torch
+    lib, r = small.pkg._lib, small.renderer
+    r.camera = small.pkg.Camera()
+    want, want_vis = small.render_gpu()
+    forks = [r.fork(), r.fork()]
+    try:
+        streams = [torch.cuda.Stream() for _ in forks]
+        outs = [torch.zeros((small.height, small.width, 4), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        for f, st in zip(forks, streams):
+            f.set_stream(st.cuda_stream)
+        views = []
+        for k in range(6):                                  # six frames in turn over the three contexts, three camera views
+            ctx = [r] + forks
+            cam = small.pkg.Camera()
+            cam.update_camera_rotation(-100.0 * (k % 3), 30.0 * (k % 3))
+            ctx[k % 3].camera = cam
+            ctx[k % 3].draw_frame_device(outs[k % 3].data_ptr())
+            views.append(k % 3)
+        for c in [r] + forks:
+            c.synchronize()
+        for k in range(3):
+            r.camera = small.pkg.Camera()
+            r.camera.update_camera_rotation(-100.0 * k, 30.0 * k)
+            ref, _ = small.render_gpu()
+            assert (outs[k].cpu().numpy() == ref).all(), k
+        r.camera = small.pkg.Camera()
+        forks[0].camera = small.pkg.Camera()                # a fork has a camera of its own
+        assert (forks[0].draw_frame() == want).all()        # host-output path of a fork
+        img = np.zeros((4, 4, 4), np.uint8)
+        assert r._lib.pbr_upload_texture(forks[0]._ctx, 0, ob.ptr(img), 4, 4, 1, 0) == lib.PBR_E_STATE
+        assert r._lib.pbr_ibl_brdf_lut(forks[1]._ctx, 64) == lib.PBR_E_STATE
+        assert r._lib.pbr_destroy(r._ctx) == lib.PBR_E_STATE and b"forked" in r._lib.pbr_last_error(r._ctx)
+        nested = C.c_void_p()
+        assert r._lib.pbr_fork(forks[0]._ctx, C.byref(nested)) == lib.PBR_E_ARG and not nested
+        # a change made through the parent reaches the forks' next frame
+        lib.check(r._ctx, r._lib.pbr_ibl_brdf_lut(r._ctx, 64))
+        a = forks[1]; a.camera = small.pkg.Camera()
+        changed = a.draw_frame()
+        lib.check(r._ctx, r._lib.pbr_ibl_brdf_lut(r._ctx, small.oracle.lut_size))
+        assert (changed != want).any() and (a.draw_frame() == want).all()
+    finally:
+        for f in forks:
+            f.close()
+    rgba, vis = small.render_gpu()
+    assert (rgba == want).all() and (vis == want_vis).all()
+
+
 def test_error_reporting(small):
     lib, r = small.pkg._lib, small.renderer
     u = small.uniforms()

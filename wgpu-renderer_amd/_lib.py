@@ -36,6 +36,7 @@ class PbrError(RuntimeError):
 EXPORTS = {
     "pbr_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "pbr_destroy": (C.c_int, [C.c_void_p]),
+    "pbr_fork": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "pbr_last_error": (C.c_char_p, [C.c_void_p]),
     "pbr_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pbr_synchronize": (C.c_int, [C.c_void_p]),

@@ -225,8 +225,11 @@ void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
   }
 }
 
+// the context that owns the scene (mesh, textures, IBL maps): the context itself, or the one it was forked from
+PbrContext* assets_of(PbrContext* c) { return c->parent ? c->parent : c; }
+
 int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int samples) {
-  const size_t ntri = (size_t)(c->n_indices / 3) * c->n_instances;
+  const size_t ntri = (size_t)(assets_of(c)->n_indices / 3) * assets_of(c)->n_instances;
   bool grew = false;
   if (ntri > c->record_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -347,17 +350,19 @@ struct FrameWork {
 
 static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, int y0, int y1, void* d_rgba8, void* d_vis, bool want_host_vis,
                        PbrFrameStats* stats, bool static_memory = false) {
+  PbrContext* a = assets_of(c);              // scene data may belong to the context this one was forked from
+  PbrContextPrivate* apr = priv_of(a);
   if (!u) return fail(c, PBR_E_ARG, "uniforms pointer is null");
   if (W <= 0 || H <= 0 || W > 16384 || H > 16384) return fail(c, PBR_E_ARG, "bad target size %dx%d", W, H);
   if (y0 < 0 || y1 > H || y0 >= y1 || (y0 & 1) || ((y1 & 1) && y1 != H)) return fail(c, PBR_E_ARG, "bad row range [%d,%d) for height %d (rows must start and end on even lines)", y0, y1, H);
   if (u->sampler_index & ~31u) return fail(c, PBR_E_ARG, "sampler index %u: the reference builds 32 samplers (renderer.ts:822-859)", u->sampler_index);
-  if (!c->d_vsoa) return fail(c, PBR_E_STATE, "no mesh uploaded");
-  for (int i = 0; i < 5; ++i) if (!c->d_tex[i]) return fail(c, PBR_E_STATE, "material texture slot %d not uploaded", i);
-  if (!c->d_irr) return fail(c, PBR_E_STATE, "irradiance map not generated");
-  if (!c->d_pre) return fail(c, PBR_E_STATE, "prefilter map not generated");
-  if (!c->d_lut) return fail(c, PBR_E_STATE, "BRDF LUT not generated");
-  if (!c->d_sky) return fail(c, PBR_E_STATE, "skybox cube not generated");
-  if (c->has_instance_mats == false && c->n_instances != 1) return fail(c, PBR_E_STATE, "instanced mesh without instance matrices");
+  if (!a->d_vsoa) return fail(c, PBR_E_STATE, "no mesh uploaded");
+  for (int i = 0; i < 5; ++i) if (!a->d_tex[i]) return fail(c, PBR_E_STATE, "material texture slot %d not uploaded", i);
+  if (!a->d_irr) return fail(c, PBR_E_STATE, "irradiance map not generated");
+  if (!a->d_pre) return fail(c, PBR_E_STATE, "prefilter map not generated");
+  if (!a->d_lut) return fail(c, PBR_E_STATE, "BRDF LUT not generated");
+  if (!a->d_sky) return fail(c, PBR_E_STATE, "skybox cube not generated");
+  if (a->has_instance_mats == false && a->n_instances != 1) return fail(c, PBR_E_STATE, "instanced mesh without instance matrices");
   DeviceGuard guard(c->device);
   PbrContextPrivate* pr = priv_of(c);
 
@@ -372,7 +377,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     // nothing may be allocated on this path: the frame has to fit the fixed array, and everything derived from the
     // IBL maps has to exist already
     using namespace static_layout;
-    const size_t ntri = (size_t)(c->n_indices / 3) * c->n_instances;
+    const size_t ntri = (size_t)(a->n_indices / 3) * a->n_instances;
     if (msaa) return fail(c, PBR_E_UNSUPPORTED, "pbr_draw_frame_static renders the single-sample pipeline only");
     if (tiles_x * tiles_y > PBR_STATIC_MAX_TILES)
       return fail(c, PBR_E_ARG, "pbr_draw_frame_static: %d x %d pixels are %d tiles of 32 x 32, the fixed working memory holds %d (e.g. 1920 x 1080)", W, rows,
@@ -380,7 +385,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     if (ntri > PBR_STATIC_MAX_TRIANGLES)
       return fail(c, PBR_E_ARG, "pbr_draw_frame_static: %zu triangles (all instances), the fixed working memory holds %d", ntri, PBR_STATIC_MAX_TRIANGLES);
     if (c->device < 0 || c->device >= kMaxDevices || !g_scratch_ptr[c->device]) return fail(c, PBR_E_STATE, "no fixed working memory on device %d", c->device);
-    if (pr->sky_b.dirty || !pr->sky_b.d || pr->irr_b.dirty || !pr->irr_b.d || pr->pre_b.dirty || !pr->pre_b.d || pr->lut_pair_dirty || pr->lut_pair_size != c->lut_size)
+    if (apr->sky_b.dirty || !apr->sky_b.d || apr->irr_b.dirty || !apr->irr_b.d || apr->pre_b.dirty || !apr->pre_b.d || apr->lut_pair_dirty || apr->lut_pair_size != a->lut_size)
       return fail(c, PBR_E_STATE, "pbr_draw_frame_static: the lookup copies of the IBL maps are not built yet; draw one frame with pbr_draw_frame_device after the last IBL call");
     unsigned char* base = g_scratch_ptr[c->device];
     fw.counters = reinterpret_cast<uint32_t*>(base + kCounters); fw.next_counters = fw.counters + 8;
@@ -411,23 +416,30 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   fp.u = *u;
   mat4_mul_host(u->projection, u->view, fp.pv);
   fp.W = W; fp.H = H; fp.y0 = y0; fp.y1 = y1; fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
-  fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances;
-  fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
+  fp.n_verts = a->n_verts; fp.n_tris = a->n_indices / 3; fp.n_instances = a->n_instances;
+  fp.has_instance_mats = a->has_instance_mats ? 1 : 0;
   fp.msaa = msaa ? 1 : 0;
   fp.two_over_w = 2.0f / (float)W; fp.two_over_h = 2.0f / (float)H;
   const FrameParams& dp = fp;
   hipStream_t s = c->stream;
 
-  if (!static_memory && ((rc = refresh_bordered(c, pr->sky_b, c->sky)) || (rc = refresh_bordered(c, pr->irr_b, c->irr)) || (rc = refresh_bordered(c, pr->pre_b, c->pre)))) return rc;
-  if (!static_memory && (pr->lut_pair_dirty || pr->lut_pair_size != c->lut_size)) {
-    if (pr->lut_pair_size != c->lut_size) {
-      HIP_TRY(c, hipStreamSynchronize(c->stream));
-      if (pr->d_lut_pair) { (void)hipFree(pr->d_lut_pair); pr->d_lut_pair = nullptr; }
-      HIP_TRY(c, hipMalloc(&pr->d_lut_pair, (size_t)c->lut_size * c->lut_size * sizeof(uint32_t)));
-      pr->lut_pair_size = c->lut_size;
+  // The lookup copies derived from the IBL maps belong to the scene's owner and are rebuilt on its stream; a forked
+  // context that finds them stale waits for that stream before its own launches read them.
+  const bool stale = apr->sky_b.dirty || !apr->sky_b.d || apr->irr_b.dirty || !apr->irr_b.d || apr->pre_b.dirty || !apr->pre_b.d || apr->lut_pair_dirty ||
+                     apr->lut_pair_size != a->lut_size;
+  if (!static_memory && stale) {
+    if ((rc = refresh_bordered(a, apr->sky_b, a->sky)) || (rc = refresh_bordered(a, apr->irr_b, a->irr)) || (rc = refresh_bordered(a, apr->pre_b, a->pre))) return rc;
+    if (apr->lut_pair_dirty || apr->lut_pair_size != a->lut_size) {
+      if (apr->lut_pair_size != a->lut_size) {
+        HIP_TRY(c, hipStreamSynchronize(a->stream));
+        if (apr->d_lut_pair) { (void)hipFree(apr->d_lut_pair); apr->d_lut_pair = nullptr; }
+        HIP_TRY(c, hipMalloc(&apr->d_lut_pair, (size_t)a->lut_size * a->lut_size * sizeof(uint32_t)));
+        apr->lut_pair_size = a->lut_size;
+      }
+      launch_lut_pair(a->stream, a->d_lut, apr->d_lut_pair, a->lut_size);
+      apr->lut_pair_dirty = false;
     }
-    launch_lut_pair(s, c->d_lut, pr->d_lut_pair, c->lut_size);
-    pr->lut_pair_dirty = false;
+    if (a != c) HIP_TRY(c, hipStreamSynchronize(a->stream));
   }
 
   const bool timed = stats != nullptr;
@@ -439,10 +451,10 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // the specialised resolve covers the reference's default sampler on power-of-two textures
   static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
   bool fast = (u->sampler_index & 15u) == 15u;
-  for (int i = 0; i < 5; ++i) fast = fast && c->tex[i].srgb == kFormatSrgb[i];
+  for (int i = 0; i < 5; ++i) fast = fast && a->tex[i].srgb == kFormatSrgb[i];
   for (int i = 0; i < 5; ++i)
-    fast = fast && (c->tex[i].w & (c->tex[i].w - 1)) == 0 && (c->tex[i].h & (c->tex[i].h - 1)) == 0 && c->tex[i].w == c->tex[0].w &&
-           c->tex[i].h == c->tex[0].h && c->tex[i].levels == c->tex[0].levels;
+    fast = fast && (a->tex[i].w & (a->tex[i].w - 1)) == 0 && (a->tex[i].h & (a->tex[i].h - 1)) == 0 && a->tex[i].w == a->tex[0].w &&
+           a->tex[i].h == a->tex[0].h && a->tex[i].levels == a->tex[0].levels;
 
   uint32_t* counters = fw.counters;
   uint32_t* next_counters = fw.next_counters;
@@ -463,13 +475,13 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // The multisampled resolve blends over the skybox colour, which therefore has to be complete before the
   // rasteriser: all its tiles ride in the setup launch.
   SkyShare sky_b;
-  sky_b.sky = pr->sky_b.cube; sky_b.rgba8 = reinterpret_cast<uint32_t*>(color); sky_b.first = 0; sky_b.own_blocks = 0;
+  sky_b.sky = apr->sky_b.cube; sky_b.rgba8 = reinterpret_cast<uint32_t*>(color); sky_b.first = 0; sky_b.own_blocks = 0;
   sky_b.count = msaa ? n_tiles : std::min(n_tiles, std::max(0, (int)(n_tiles * share_setup)));
   const int sky_from_tile = sky_b.first + sky_b.count;
-  const VertexSource source = {nullptr, c->d_vsoa, c->d_inst_model, c->d_inst_normal};
+  const VertexSource source = {nullptr, a->d_vsoa, a->d_inst_model, a->d_inst_normal};
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
-  launch_setup_and_bin(s, dp, source, c->d_indices, fw.setup, fw.records, (uint32_t)fw.setup_cap, fw.tile_count, fw.bins, fw.overflow,
-                       (uint32_t)fw.overflow_cap, counters, c->n_indices / 3, c->n_instances, sky_b);
+  launch_setup_and_bin(s, dp, source, a->d_indices, fw.setup, fw.records, (uint32_t)fw.setup_cap, fw.tile_count, fw.bins, fw.overflow,
+                       (uint32_t)fw.overflow_cap, counters, a->n_indices / 3, a->n_instances, sky_b);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
   // the visibility buffer is only written when someone will read it: the caller (vis output) or the
@@ -480,15 +492,15 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
                        counters, next_counters, c->d_tile_live, write_vis || c->capture_depth, tiles_x, tiles_y);
   else
     launch_raster(s, dp, fw.setup, fw.tile_count, fw.bins, fw.overflow, (uint32_t)fw.overflow_cap, vis, (c->capture_depth && !static_memory) ? c->d_depth : nullptr,
-                  counters, next_counters, fw.lists, write_vis, pr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
+                  counters, next_counters, fw.lists, write_vis, apr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
 
   ResolveInputs in;
-  in.records = fw.records; in.vout = c->d_vout; in.indices = c->d_indices;
-  for (int i = 0; i < 5; ++i) in.tex[i] = c->tex[i];
-  in.irr = c->irr; in.pre = c->pre; in.sky = c->sky;
-  in.irr_b = pr->irr_b.cube; in.pre_b = pr->pre_b.cube; in.sky_b = pr->sky_b.cube;
-  in.lut = c->d_lut; in.lut_pair = pr->d_lut_pair; in.lut_size = c->lut_size;
+  in.records = fw.records; in.vout = a->d_vout; in.indices = a->d_indices;
+  for (int i = 0; i < 5; ++i) in.tex[i] = a->tex[i];
+  in.irr = a->irr; in.pre = a->pre; in.sky = a->sky;
+  in.irr_b = apr->irr_b.cube; in.pre_b = apr->pre_b.cube; in.sky_b = apr->sky_b.cube;
+  in.lut = a->d_lut; in.lut_pair = apr->d_lut_pair; in.lut_size = a->lut_size;
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
   if (msaa) launch_surface_msaa(s, dp, in, pr->d_srgb_lut, vis, c->d_tile_live, color, W, rows, fast);
   else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, fw.lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
@@ -572,8 +584,24 @@ int pbr_create(int device_ordinal, PbrContext** ctx_out) {
   return PBR_OK;
 }
 
+int pbr_fork(PbrContext* parent, PbrContext** ctx_out) {
+  if (!ctx_out) return fail(parent, PBR_E_ARG, "ctx_out is null");
+  *ctx_out = nullptr;
+  if (!parent) return fail(nullptr, PBR_E_ARG, "parent context is null");
+  if (parent->parent) return fail(parent, PBR_E_ARG, "fork the context that owns the scene, not one of its forks");
+  PbrContext* child = nullptr;
+  const int rc = pbr_create(parent->device, &child);
+  if (rc) return fail(parent, rc, "%s", pbr_last_error(nullptr));
+  child->parent = parent;
+  ++parent->children;
+  *ctx_out = child;
+  return PBR_OK;
+}
+
 int pbr_destroy(PbrContext* c) {
   if (!c) return PBR_OK;
+  if (c->children > 0) return fail(c, PBR_E_STATE, "%d forked context(s) still draw from this one: destroy them first", c->children);
+  if (c->parent) { --c->parent->children; c->parent = nullptr; }
   DeviceGuard guard(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   PbrContextPrivate* pr = priv_of(c);
@@ -620,6 +648,7 @@ int pbr_synchronize(PbrContext* c) {
 // frame against hundreds of megabytes of pixel traffic, and one width keeps one set of kernels.
 static int upload_mesh_common(PbrContext* c, const float* verts, int32_t n_verts, const uint16_t* idx16, const uint32_t* idx32, int32_t n_indices,
                               int32_t instance_count, const float* instance_model, const float* instance_normal) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c) return PBR_E_ARG;
   if (!verts || (!idx16 && !idx32) || n_verts <= 0 || n_indices <= 0) return fail(c, PBR_E_ARG, "empty mesh");
   if (n_indices % 3) return fail(c, PBR_E_ARG, "index count %d is not a multiple of 3 (triangle-list)", n_indices);
@@ -670,6 +699,7 @@ int pbr_upload_mesh_u32(PbrContext* c, const float* verts, int32_t n_verts, cons
 }
 
 int pbr_upload_texture(PbrContext* c, int slot, const uint8_t* rgba8, int32_t w, int32_t h, int32_t is_srgb, int32_t gen_mips) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c) return PBR_E_ARG;
   if (slot < 0 || slot > 4) return fail(c, PBR_E_ARG, "texture slot %d out of range", slot);
   if (!rgba8 || w <= 0 || h <= 0 || w > 16384 || h > 16384) return fail(c, PBR_E_ARG, "bad texture %dx%d", w, h);
@@ -697,6 +727,7 @@ int pbr_upload_texture(PbrContext* c, int slot, const uint8_t* rgba8, int32_t w,
 }
 
 int pbr_upload_hdr(PbrContext* c, const float* rgba32f, int32_t w, int32_t h) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c) return PBR_E_ARG;
   if (!rgba32f || w <= 0 || h <= 0 || w > 32768 || h > 32768) return fail(c, PBR_E_ARG, "bad HDR %dx%d", w, h);
   DeviceGuard guard(c->device);
@@ -718,6 +749,7 @@ int pbr_upload_hdr(PbrContext* c, const float* rgba32f, int32_t w, int32_t h) {
 }
 
 int pbr_ibl_equirect_to_cube(PbrContext* c, int32_t size) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c) return PBR_E_ARG;
   if (size <= 0 || size > 8192) return fail(c, PBR_E_ARG, "bad cube size %d", size);
   if (!c->d_hdr) return fail(c, PBR_E_STATE, "no HDR uploaded");
@@ -737,6 +769,7 @@ int pbr_ibl_equirect_to_cube(PbrContext* c, int32_t size) {
 }
 
 int pbr_ibl_irradiance(PbrContext* c, int32_t size) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c) return PBR_E_ARG;
   if (size <= 0 || size > 2048) return fail(c, PBR_E_ARG, "bad cube size %d", size);
   if (!c->d_hdr) return fail(c, PBR_E_STATE, "no HDR uploaded");
@@ -767,6 +800,7 @@ int pbr_ibl_irradiance(PbrContext* c, int32_t size) {
 }
 
 int pbr_ibl_prefilter_shard_range(PbrContext* c, int32_t shard_index, int32_t shard_count, size_t* begin, size_t* end) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c || !begin || !end) return PBR_E_ARG;
   if (shard_count < 1 || shard_index < 0 || shard_index >= shard_count) return fail(c, PBR_E_ARG, "bad shard %d of %d", shard_index, shard_count);
   if (!c->d_pre) return fail(c, PBR_E_STATE, "prefilter map not allocated; call pbr_ibl_prefilter first");
@@ -798,6 +832,7 @@ int pbr_ibl_prefilter_kept_samples(int32_t mips, int32_t level, int32_t* kept) {
 
 // Filters texels [begin, end) of the flattened (mip, face, y, x) order; end == 0 stands for the whole map.
 static int prefilter_texel_range(PbrContext* c, int32_t size, int32_t mips, int32_t samples, uint64_t begin, uint64_t end, int shard_index, int shard_count) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c) return PBR_E_ARG;
   if (size <= 0 || size > 8192) return fail(c, PBR_E_ARG, "bad cube size %d", size);
   if (mips < 1 || mips > PBR_MAX_LEVELS || (size >> (mips - 1)) < 1) return fail(c, PBR_E_ARG, "bad mip count %d for size %d", mips, size);
@@ -858,6 +893,7 @@ int pbr_ibl_prefilter_texels(PbrContext* c, int32_t size, int32_t mips, int32_t 
 }
 
 int pbr_ibl_brdf_lut(PbrContext* c, int32_t size) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c) return PBR_E_ARG;
   if (size < 2 || size > 8192) return fail(c, PBR_E_ARG, "bad LUT size %d", size);
   DeviceGuard guard(c->device);
@@ -874,6 +910,7 @@ int pbr_ibl_brdf_lut(PbrContext* c, int32_t size) {
 }
 
 static int map_level(PbrContext* c, int which, int level, const void** ptr, int* w, int* h, int* layers, size_t* bytes) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   switch (which) {
     case PBR_MAP_SKYBOX:
     case PBR_MAP_IRRADIANCE:
@@ -926,6 +963,7 @@ int pbr_ibl_download(PbrContext* c, int which, int32_t level, void* out, size_t 
 }
 
 int pbr_ibl_device_ptr(PbrContext* c, int which, void** dev_ptr, size_t* total_bytes) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c || !dev_ptr) return PBR_E_ARG;
   size_t bytes = 0;
   void* p = nullptr;
@@ -984,6 +1022,7 @@ int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t 
 }
 
 int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip, float* world, float* normal) {
+  if (c && c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
   if (!c || !u) return PBR_E_ARG;
   if (!c->d_vsoa) return fail(c, PBR_E_STATE, "no mesh uploaded");
   DeviceGuard guard(c->device);

@@ -110,6 +110,8 @@ struct FrameParams {
 
 struct PbrContext {
   int device = 0;
+  PbrContext* parent = nullptr;   // set in a forked context: the scene (mesh, textures, IBL maps) is the parent's
+  int children = 0;               // forks alive
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   std::string error;

@@ -44,6 +44,8 @@ class Renderer:
         self._lib = None
         self._ctx = C.c_void_p()
         self._ready = False
+        self._forks = []        # renderers forked from this one (they share its scene on the device)
+        self._parent = None
 
     # ---- lifetime -------------------------------------------------------------------------
     def _open(self):
@@ -54,10 +56,32 @@ class Renderer:
                 self._ctx = C.c_void_p()
                 raise _lib.PbrError(rc, (self._lib.pbr_last_error(None) or b"").decode())
 
+    def fork(self):
+        """A renderer that draws this renderer's scene from the same device copy of it (pbr_fork): its own
+        camera, stream and working buffers, for keeping several frames in flight.  Close it before this one."""
+        if not self._ready:
+            self.init()
+        other = Renderer.__new__(Renderer)
+        other.__dict__.update(self.__dict__)
+        other.camera = Camera()
+        other.texture_options = dict(self.texture_options)
+        other.msaa_options = dict(self.msaa_options)
+        other._ctx = C.c_void_p()
+        other._forks = []
+        other._parent = self
+        self._check(self._lib.pbr_fork(self._ctx, C.byref(other._ctx)))
+        self._forks.append(other)
+        return other
+
     def close(self):
+        for f in list(getattr(self, "_forks", [])):
+            f.close()
         if self._lib is not None and self._ctx:
             self._lib.pbr_destroy(self._ctx)
             self._ctx = C.c_void_p()
+            parent = getattr(self, "_parent", None)
+            if parent is not None and self in parent._forks:
+                parent._forks.remove(self)
         self._ready = False
 
     def __del__(self):
