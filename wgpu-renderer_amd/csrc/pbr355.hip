@@ -225,6 +225,18 @@ void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
   }
 }
 
+// The skybox pass unprojects every pixel centre: x_ndc = (x + 0.5) 2 / W - 1, y_ndc = 1 - (y + 0.5) 2 / H, then
+// inv_view_proj * (x_ndc, y_ndc, 1, 1) (skybox.wgsl:13-27).  That is affine in the pixel coordinates; the three vectors
+// are worked out here in double precision and rounded once.
+void sky_affine(const float* m, int W, int H, FrameParams& fp) {
+  for (int r = 0; r < 4; ++r) {
+    const double c0 = m[r], c1 = m[4 + r], c2 = m[8 + r], c3 = m[12 + r];
+    fp.sky_a[r] = (float)(c0 * (1.0 / W - 1.0) + c1 * (1.0 - 1.0 / H) + c2 + c3);
+    fp.sky_bx[r] = (float)(c0 * 2.0 / W);
+    fp.sky_by[r] = (float)(-c1 * 2.0 / H);
+  }
+}
+
 // the context that owns the scene (mesh, textures, IBL maps): the context itself, or the one it was forked from
 PbrContext* assets_of(PbrContext* c) { return c->parent ? c->parent : c; }
 
@@ -420,6 +432,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   fp.has_instance_mats = a->has_instance_mats ? 1 : 0;
   fp.msaa = msaa ? 1 : 0;
   fp.two_over_w = 2.0f / (float)W; fp.two_over_h = 2.0f / (float)H;
+  sky_affine(u->inv_view_proj, W, H, fp);
   const FrameParams& dp = fp;
   hipStream_t s = c->stream;
 
@@ -1042,6 +1055,7 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances; fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
   fp.msaa = 0;
   fp.two_over_w = 2.0f / 32.0f; fp.two_over_h = 2.0f / 32.0f;
+  sky_affine(u->inv_view_proj, 32, 32, fp);
   SkyShare none = {};
   launch_vertex_stage(c->stream, fp, c->d_vsoa, c->d_inst_model, c->d_inst_normal, c->d_vout, c->n_verts, c->n_instances, none);
   HIP_TRY(c, hipStreamSynchronize(c->stream));

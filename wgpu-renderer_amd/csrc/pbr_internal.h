@@ -106,6 +106,8 @@ struct FrameParams {
   int32_t has_instance_mats;
   int32_t msaa;             // 1 = four samples per pixel (bit 16 of the sampler index, renderer.ts:1927-1932)
   float two_over_w, two_over_h;   // 2 / W, 2 / H (one correctly rounded division each, done once on the host)
+  // skybox.wgsl:25-27: inv_view_proj * (x_ndc, y_ndc, 1, 1) of pixel (x, y) is sky_a + x * sky_bx + y * sky_by
+  float sky_a[4], sky_bx[4], sky_by[4];
 };
 
 struct PbrContext {

@@ -30,11 +30,12 @@ PBR_DEV uint32_t pack_color(V3 color) {
   // pow(c, 1/2.2) as exp2(log2(c) / 2.2) (shader.wgsl:157, skybox.wgsl:30): 0 -> 0, negative or NaN -> NaN -> 0
   // unorm8 conversion: v_cvt_pk_u8_f32 rounds to nearest even, saturates to [0, 255], turns NaN into 0 and drops
   // the byte into place, which is the whole of "clamp, scale, round, pack" in one instruction per channel
-  const float g = 1.0f / 2.2f;
+  // the scale to 0..255 rides in the exponent: 255 c^(1/2.2) = exp2(log2(c) / 2.2 + log2(255))
+  const float g = 1.0f / 2.2f, k = 7.994353436858858f;
   uint32_t packed = 0xff000000u;
-  packed = __builtin_amdgcn_cvt_pk_u8_f32(exp2_fast(log2_fast(color.x) * g) * 255.0f, 0u, packed);
-  packed = __builtin_amdgcn_cvt_pk_u8_f32(exp2_fast(log2_fast(color.y) * g) * 255.0f, 1u, packed);
-  packed = __builtin_amdgcn_cvt_pk_u8_f32(exp2_fast(log2_fast(color.z) * g) * 255.0f, 2u, packed);
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(exp2_fast(fmaf(log2_fast(color.x), g, k)), 0u, packed);
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(exp2_fast(fmaf(log2_fast(color.y), g, k)), 1u, packed);
+  packed = __builtin_amdgcn_cvt_pk_u8_f32(exp2_fast(fmaf(log2_fast(color.z), g, k)), 2u, packed);
   return packed;
 }
 
@@ -89,6 +90,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct CubeFootPair { uint32_t o[2]; uint32_t m; f2 w[4]; };   // element k of each weight belongs to the pixel with offset o[k]
 
+// min(max(x, -1), top) for a wave-uniform top >= -1, as the single median instruction it is
+PBR_DEV int clamp_from_minus_one(int x, int top) {
+  int r;
+  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(x), "s"(top));
+  return r;
+}
+
 // cube_foot on level 0 for two lookups at once (faces and face coordinates given per element).
 PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int face1, f2 sc, f2 tc, f2 rc) {
 #pragma clang fp contract(fast)
@@ -102,8 +110,10 @@ PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int f
   const f2 a = tu - fu, b = tv - fv;
   const f2 oma = 1.0f - a, omb = 1.0f - b;
   f.w[0] = oma * omb; f.w[1] = a * omb; f.w[2] = oma * b; f.w[3] = a * b;
-  const int i0 = min(max((int)fu.x, -1), n - 1), j0 = min(max((int)fv.x, -1), n - 1);
-  const int i1 = min(max((int)fu.y, -1), n - 1), j1 = min(max((int)fv.y, -1), n - 1);
+  // (one v_med3_i32 each; the coordinates are in range by construction, the clamp only keeps a NaN or an overflow inside the map)
+  const int top = __builtin_amdgcn_readfirstlane(n - 1);   // the same in every lane
+  const int i0 = clamp_from_minus_one((int)fu.x, top), j0 = clamp_from_minus_one((int)fv.x, top);
+  const int i1 = clamp_from_minus_one((int)fu.y, top), j1 = clamp_from_minus_one((int)fv.y, top);
   // texel index with 24-bit multiply-adds (face * m + row and m are far below 2^24 for any cube the library accepts)
   f.o[0] = bordered.off[0] + __umul24(__umul24((uint32_t)face0, (uint32_t)m) + (uint32_t)(j0 + 1), (uint32_t)m) + (uint32_t)(i0 + 1);
   f.o[1] = bordered.off[0] + __umul24(__umul24((uint32_t)face1, (uint32_t)m) + (uint32_t)(j1 + 1), (uint32_t)m) + (uint32_t)(i1 + 1);
@@ -123,9 +133,10 @@ PBR_DEV V3 weigh4_of_pair(const Rgb t[4], const f2 w[4]) {
 // pack_color for two pixels: the two multiplies of each channel run two-wide.
 PBR_DEV void pack_color_pair(V3 c0, V3 c1, uint32_t& out0, uint32_t& out1) {
 #pragma clang fp contract(fast)
-  const float g = 1.0f / 2.2f;
-  const f2 lx = (f2){log2_fast(c0.x), log2_fast(c1.x)} * g, ly = (f2){log2_fast(c0.y), log2_fast(c1.y)} * g, lz = (f2){log2_fast(c0.z), log2_fast(c1.z)} * g;
-  const f2 ex = (f2){exp2_fast(lx.x), exp2_fast(lx.y)} * 255.0f, ey = (f2){exp2_fast(ly.x), exp2_fast(ly.y)} * 255.0f, ez = (f2){exp2_fast(lz.x), exp2_fast(lz.y)} * 255.0f;
+  // 255 c^(1/2.2) = exp2(log2(c) / 2.2 + log2(255)): one multiply-add per channel pair between the two transcendentals
+  const float g = 1.0f / 2.2f, k = 7.994353436858858f;
+  const f2 lx = (f2){log2_fast(c0.x), log2_fast(c1.x)} * g + k, ly = (f2){log2_fast(c0.y), log2_fast(c1.y)} * g + k, lz = (f2){log2_fast(c0.z), log2_fast(c1.z)} * g + k;
+  const f2 ex = {exp2_fast(lx.x), exp2_fast(lx.y)}, ey = {exp2_fast(ly.x), exp2_fast(ly.y)}, ez = {exp2_fast(lz.x), exp2_fast(lz.y)};
   uint32_t p0 = 0xff000000u, p1 = 0xff000000u;
   p0 = __builtin_amdgcn_cvt_pk_u8_f32(ex.x, 0u, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(ex.y, 0u, p1);
   p0 = __builtin_amdgcn_cvt_pk_u8_f32(ey.x, 1u, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(ey.y, 1u, p1);
@@ -141,18 +152,18 @@ PBR_DEV void pack_color_pair(V3 c0, V3 c1, uint32_t& out0, uint32_t& out1) {
 // it) the other three take the full selection again.
 PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sky, int x0, int y, uint32_t out[4]) {
 #pragma clang fp contract(fast)
-  const float* m = p->u.inv_view_proj;
-  const float two_over_w = p->two_over_w;
-  const float yn = 1.0f - ((float)y + 0.5f) * p->two_over_h;
-  const float xn = ((float)x0 + 0.5f) * two_over_w - 1.0f;
+  // inverse view-projection applied to the pixel centre's clip position (skybox.wgsl:25-27), as the affine function of
+  // the pixel coordinates it is: t(x, y) = a + x bx + y by, the three vectors prepared once per frame on the host
+  const float* ta = p->sky_a; const float* tbx = p->sky_bx; const float* tby = p->sky_by;
+  const float fx = (float)x0, fy = (float)y;
+  const float tx = fmaf(fx, tbx[0], fmaf(fy, tby[0], ta[0])), ty = fmaf(fx, tbx[1], fmaf(fy, tby[1], ta[1]));
+  const float tz = fmaf(fx, tbx[2], fmaf(fy, tby[2], ta[2])), tw = fmaf(fx, tbx[3], fmaf(fy, tby[3], ta[3]));
   // normalize(xyz / w) only rescales the lookup direction by 1 / (w |xyz|); the cube lookup depends on
   // the direction alone, so only the sign of w is applied.
-  const float tx = ((m[0] * xn + m[4] * yn) + m[8]) + m[12], ty = ((m[1] * xn + m[5] * yn) + m[9]) + m[13];
-  const float tz = ((m[2] * xn + m[6] * yn) + m[10]) + m[14], tw = ((m[3] * xn + m[7] * yn) + m[11]) + m[15];
   const float sg = tw < 0.0f ? -1.0f : 1.0f;
   const V3 d0 = v3(tx * sg, ty * sg, -(tz * sg));
-  const V3 step = v3(m[0] * two_over_w * sg, m[1] * two_over_w * sg, -(m[2] * two_over_w * sg));
-  const float w_step = m[3] * two_over_w;
+  const V3 step = v3(tbx[0] * sg, tbx[1] * sg, -(tbx[2] * sg));
+  const float w_step = tbx[3];
   const CubeCoord first = cube_select(d0);
   float dsc, dtc, drc;
   cube_face_coords(first.face, step, dsc, dtc, drc);
@@ -174,8 +185,8 @@ PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sk
 #pragma unroll
     for (int k = 1; k < 4; ++k) {
       const float wk = tw + (float)k * w_step;
-      const float sk = wk < 0.0f ? -1.0f : 1.0f, xk = xn + (float)k * two_over_w;
-      const float ax = ((m[0] * xk + m[4] * yn) + m[8]) + m[12], ay = ((m[1] * xk + m[5] * yn) + m[9]) + m[13], az = ((m[2] * xk + m[6] * yn) + m[10]) + m[14];
+      const float sk = wk < 0.0f ? -1.0f : 1.0f;
+      const float ax = fmaf((float)k, tbx[0], tx), ay = fmaf((float)k, tbx[1], ty), az = fmaf((float)k, tbx[2], tz);
       c[k] = cube_select(v3(ax * sk, ay * sk, -(az * sk)));
       face[k] = c[k].face;
     }
