@@ -187,6 +187,10 @@ int pbr_draw_frame_static(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w,
 /* Stage outputs for verification: clip[n][4], world[n][3], normal[n][3] of vs_main
  * (shader.wgsl:37-47) for n = instance_count*n_verts, and the f32 depth buffer of the last frame. */
 int pbr_debug_vertex_stage(PbrContext* ctx, const PbrFrameUniforms* u, float* clip, float* world, float* normal);
+/* One level of an uploaded material texture as the device holds it after generateMipmaps (renderer.ts:1103-1321):
+ * w x h rgba8, top row first; rgba8_out == NULL only reports the level's size.  For verification of the mip chain
+ * (the per-level 8-bit rounding and, for the sRGB formats, the decode - average - encode of every level). */
+int pbr_debug_texture_level(PbrContext* ctx, int slot, int32_t level, uint8_t* rgba8_out, size_t out_bytes, int32_t* w, int32_t* h);
 /* The depth buffer normally lives only in on-chip memory during rasterisation; enable capture to
  * have the following frames also write it to device memory so pbr_debug_depth can return it. */
 int pbr_debug_capture_depth(PbrContext* ctx, int32_t enable);

@@ -89,6 +89,16 @@ inline int wrap(int i, int n, bool repeat) {
 
 struct Tex8 { const uint8_t* chain; int w, h, levels; bool srgb; };
 
+// Test instrumentation, not part of the restated pipeline: the smallest distance of any DISCRETE sampling decision of
+// the pixel being shaded from its switching point - the level switch of a "nearest" mipmap filter at lambda = k + 1/2
+// (in levels), the min / mag filter switch at lambda = 0 when the two filters differ (in levels), the texel switch of a
+// "nearest" texel filter (in texels).  A pixel whose margin is tiny may legitimately come out differently on an
+// implementation whose derivatives or log2 differ in the last bits; the parity tests use this to show that every pixel
+// beyond the colour tolerance is such a pixel.
+static thread_local float t_margin = 1e30f;
+inline void note_margin(float m) { if (m == m && m < t_margin) t_margin = m; }
+inline float to_nearest_integer(float v) { return std::fabs(v - std::nearbyint(v)); }
+
 inline V4 texel8(const Tex8& t, int level, int x, int y) {
   const uint8_t* p = t.chain + 4 * (chain_off(t.w, t.h, level) + (int64_t)y * level_dim(t.w, level) + x);
   if (t.srgb) return {g_srgb_lut[p[0]], g_srgb_lut[p[1]], g_srgb_lut[p[2]], (float)p[3] / 255.0f};
@@ -111,14 +121,17 @@ V4 sample_2d(const Tex8& t, uint32_t sampler_index, V2 uv, V2 ddx, V2 ddy) {
   float rho = std::max(std::sqrt(mux * mux + mvx * mvx), std::sqrt(muy * muy + mvy * mvy));
   float lambda = std::log2(rho);                       // -inf for rho = 0
   if (std::isnan(lambda)) lambda = 0.0f;
+  if (mag_lin != min_lin) note_margin(std::fabs(lambda));
   lambda = std::min(std::max(lambda, 0.0f), 32.0f);    // sampler lodMinClamp / lodMaxClamp defaults
   const bool linear = lambda <= 0.0f ? mag_lin : min_lin;
   lambda = std::min(lambda, (float)(t.levels - 1));
+  if (t.levels > 1 && lambda < (float)(t.levels - 1)) note_margin(std::fabs(lambda + 0.5f - std::nearbyint(lambda + 0.5f)));
   int level = (int)std::ceil(lambda + 0.5f) - 1;       // mipmapFilter defaults to "nearest"
   level = std::min(std::max(level, 0), t.levels - 1);
   int lw = level_dim(t.w, level), lh = level_dim(t.h, level);
   if (std::isnan(uv.x) || std::isnan(uv.y)) { float n = std::nanf(""); return {n, n, n, n}; }
   if (!linear) {
+    note_margin(std::min(to_nearest_integer(uv.x * (float)lw), to_nearest_integer(uv.y * (float)lh)));
     int x = wrap((int)std::floor(uv.x * (float)lw), lw, rep_u), y = wrap((int)std::floor(uv.y * (float)lh), lh, rep_v);
     return texel8(t, level, x, y);
   }
@@ -138,6 +151,7 @@ V4 sample_lut(const uint16_t* lut, int size, uint32_t sampler_index, V2 uv, V2 d
   float rho = std::max(std::sqrt(mux * mux + mvx * mvx), std::sqrt(muy * muy + mvy * mvy));
   float lambda = std::log2(rho);
   if (std::isnan(lambda)) lambda = 0.0f;
+  if (mag_lin != min_lin) note_margin(std::fabs(lambda));
   lambda = std::min(std::max(lambda, 0.0f), 32.0f);
   const bool linear = lambda <= 0.0f ? mag_lin : min_lin;   // the single level is used either way
   auto tx = [&](int x, int y) -> V4 {
@@ -145,7 +159,10 @@ V4 sample_lut(const uint16_t* lut, int size, uint32_t sampler_index, V2 uv, V2 d
     return {orc_f16_to_f32(p[0]), orc_f16_to_f32(p[1]), orc_f16_to_f32(p[2]), orc_f16_to_f32(p[3])};
   };
   if (std::isnan(uv.x) || std::isnan(uv.y)) { float n = std::nanf(""); return {n, n, n, n}; }
-  if (!linear) return tx(wrap((int)std::floor(uv.x * fs), size, rep_u), wrap((int)std::floor(uv.y * fs), size, rep_v));
+  if (!linear) {
+    note_margin(std::min(to_nearest_integer(uv.x * fs), to_nearest_integer(uv.y * fs)));
+    return tx(wrap((int)std::floor(uv.x * fs), size, rep_u), wrap((int)std::floor(uv.y * fs), size, rep_v));
+  }
   float tu = uv.x * fs - 0.5f, tv = uv.y * fs - 0.5f;
   float fu = std::floor(tu), fv = std::floor(tv);
   int x0 = wrap((int)fu, size, rep_u), x1 = wrap((int)fu + 1, size, rep_u);
@@ -674,7 +691,7 @@ Ctx make_ctx(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H) {
 // ("center" interpolation, the WGSL default), the 8-bit result is what its samples store, and the
 // resolve averages the stored values (round half to even; the rounding of a multisample resolve is
 // left to the implementation).  The skybox triangle covers the samples no geometry claimed.
-void shade_impl(Ctx& cx, int y0, int y1, int samples, const uint32_t* vis, uint8_t* rgba8) {
+void shade_impl(Ctx& cx, int y0, int y1, int samples, const uint32_t* vis, uint8_t* rgba8, float* margin = nullptr) {
   const OrcScene* sc = cx.sc;
   const OrcFrameUniforms* u = cx.u;
   Material m;
@@ -688,9 +705,11 @@ void shade_impl(Ctx& cx, int y0, int y1, int samples, const uint32_t* vis, uint8
   for (int y = y0; y < y1; ++y)
     for (int x = 0; x < W; ++x) {
       int64_t o = (int64_t)(y - y0) * W + x;
+      t_margin = 1e30f;
       if (samples == 1) {
         if (vis[o]) shade_pixel(cx, m, irr, pre, vis[o] - 1, x, y, rgba8 + 4 * o);
         else shade_sky(cx, sky, x, y, rgba8 + 4 * o);
+        if (margin) margin[o] = t_margin;
         continue;
       }
       const uint32_t* ids = vis + o * samples;
@@ -712,6 +731,7 @@ void shade_impl(Ctx& cx, int y0, int y1, int samples, const uint32_t* vis, uint8
         rgba8[4 * o + k] = (uint8_t)q;
       }
       rgba8[4 * o + 3] = 255;
+      if (margin) margin[o] = t_margin;
     }
 }
 
@@ -749,6 +769,15 @@ void orc_draw_frame(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H,
   if (!vis) { v.resize((size_t)(y1 - y0) * W * samples); vis = v.data(); }
   raster_impl(cx, y0, y1, samples, vis, d.data());
   shade_impl(cx, y0, y1, samples, vis, rgba8);
+}
+
+// orc_draw_frame plus, per pixel, the decision margin described at note_margin (1e30 where no discrete decision was taken).
+void orc_draw_frame_margins(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int y0, int y1, uint8_t* rgba8, uint32_t* vis, float* margin) {
+  Ctx cx = make_ctx(sc, u, W, H);
+  const int samples = sample_count(u);
+  std::vector<float> d((size_t)(y1 - y0) * W * samples);
+  raster_impl(cx, y0, y1, samples, vis, d.data());
+  shade_impl(cx, y0, y1, samples, vis, rgba8, margin);
 }
 
 void orc_sample_cube(const float* chain, int size, int levels, const float* dir3, float lod, float* rgba_out) {

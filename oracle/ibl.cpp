@@ -107,6 +107,37 @@ inline uint8_t to_unorm8(float x) {
   return (uint8_t)std::nearbyint(x * 255.0f);
 }
 
+// Store of a linear value into an 8-bit sRGB texel (the render-target write of generateMipmaps into an
+// rgba8unorm-srgb level, renderer.ts:1263-1290): the EXACTLY rounded code.  WebGPU / Vulkan leave the encode to the
+// implementation within a tolerance, and pow() of two math libraries differs by an ulp, which flips a byte now and then;
+// so the code is defined without pow: code k is stored when T[k] <= v < T[k + 1], T[k] being the linear value whose
+// encoding is k - 1/2, worked out in double precision and rounded up to the next float.  The float formula only
+// proposes a candidate, the table decides.
+inline const float* srgb_store_thresholds() {
+  static float T[257];
+  static bool ready = false;
+  if (!ready) {
+    T[0] = 0.0f;
+    for (int k = 1; k <= 255; ++k) {
+      const double c = ((double)k - 0.5) / 255.0;
+      const double lin = c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4);
+      float f = (float)lin;
+      if ((double)f < lin) f = std::nextafterf(f, 2.0f);
+      T[k] = f;
+    }
+    T[256] = 3.0e38f;
+    ready = true;
+  }
+  return T;
+}
+inline uint8_t linear_to_srgb8(float v) {
+  const float* T = srgb_store_thresholds();
+  int k = (int)to_unorm8(linear_to_srgb(v));
+  while (k < 255 && v >= T[k + 1]) ++k;
+  while (k > 0 && !(v >= T[k])) --k;
+  return (uint8_t)k;
+}
+
 }  // namespace
 
 extern "C" {
@@ -295,6 +326,7 @@ void orc_build_mips_rgba32f(float* chain, int w, int h, int levels) {
 }
 
 void orc_build_mips_rgba8(uint8_t* chain, int w, int h, int levels, int is_srgb) {
+  srgb_store_thresholds();   // built before the parallel loops
   float lut[256];
   for (int i = 0; i < 256; ++i) { float c = (float)i / 255.0f; lut[i] = is_srgb ? srgb_to_linear(c) : c; }
   for (int l = 1; l < levels; ++l) {
@@ -315,7 +347,8 @@ void orc_build_mips_rgba8(uint8_t* chain, int w, int h, int levels, int is_srgb)
             v = (((float)s00 / 255.0f * w00 + (float)s10 / 255.0f * w10) + (float)s01 / 255.0f * w01) + (float)s11 / 255.0f * w11;
           } else {
             v = ((lut[s00] * w00 + lut[s10] * w10) + lut[s01] * w01) + lut[s11] * w11;
-            v = linear_to_srgb(v);
+            dst[4 * ((int64_t)y * dw + x) + c] = linear_to_srgb8(v);
+            continue;
           }
           dst[4 * ((int64_t)y * dw + x) + c] = to_unorm8(v);
         }
@@ -409,6 +442,117 @@ void orc_prefilter(const float* chain, int w, int h, int levels, int size, float
       }
     }
     out[4 * t + 0] = cr / total_weight; out[4 * t + 1] = cg / total_weight; out[4 * t + 2] = cb / total_weight; out[4 * t + 3] = 1.0f;
+  }
+}
+
+/* ---------------- test instrumentation: which results are reachable -------------------------------------------------
+ * The three cube generators read NEAREST equirect pixels (textureLoad of a truncated coordinate).  A sample whose
+ * coordinate lies within rounding distance of a pixel boundary legitimately lands on either side on another
+ * implementation (atan2 / asin / the direction itself differ in the last bits), and next to the 5 000-nit sun one such
+ * flip moves a texel far beyond any relative tolerance.  These variants compute, per output texel, the interval
+ * [lo, hi] of values reachable when every sample within `ang` radians of a boundary may take either pixel.  They are
+ * not part of the restated pipeline; the parity tests use them to show that a texel outside the tolerance is such a
+ * texel - and by how much the interval had to be used. */
+struct PixelRange { int x0, x1, y0, y1; };
+inline PixelRange equirect_pixel_range(V3 d, int w, int h, float ang) {
+  int px, py; equirect_pixel(d, w, h, &px, &py);
+  PixelRange r = {px, px, py, py};
+  if (!(d.x == d.x) || !(d.y == d.y) || !(d.z == d.z)) return r;   // NaN direction: pixel 0 by rule
+  const float rxz = std::sqrt(d.x * d.x + d.z * d.z), ry = std::sqrt(std::max(1.0f - d.y * d.y, 0.0f));
+  const float su = (ang / std::max(rxz, 1e-20f) + ang) * INV_ATAN_X + 1.2e-7f, sv = (ang / std::max(ry, 1e-20f) + ang) * INV_ATAN_Y + 1.2e-7f;
+  const float u = std::atan2(d.z, d.x) * INV_ATAN_X + 0.5f, v = std::asin(std::min(std::max(d.y, -1.0f), 1.0f)) * INV_ATAN_Y + 0.5f;
+  auto pixel = [](float coord, int n) { return (int)(std::min(std::max(coord, 0.0f), 1.0f) * (float)n) >= n ? n - 1 : (int)(std::min(std::max(coord, 0.0f), 1.0f) * (float)n); };
+  if (!(u - su >= 0.0f) || !(u + su <= 0.99983f)) { r.x0 = 0; r.x1 = w - 1; }    // the seam (or a pole): the angle may wrap to the other end of the row
+  else { r.x0 = pixel(u - su, w); r.x1 = pixel(u + su, w); }
+  r.y0 = pixel(v - sv, h); r.y1 = pixel(v + sv, h);
+  r.x0 = std::min(r.x0, px); r.x1 = std::max(r.x1, px); r.y0 = std::min(r.y0, py); r.y1 = std::max(r.y1, py);   // the nominal pixel is always a candidate
+  return r;
+}
+inline void range_min_max(const float* level, int w, const PixelRange& r, float* mn, float* mx) {
+  for (int c = 0; c < 3; ++c) { mn[c] = 1e30f; mx[c] = -1e30f; }
+  for (int y = r.y0; y <= r.y1; ++y)
+    for (int x = r.x0; x <= r.x1; ++x) {
+      const float* t = level + 4 * ((int64_t)y * w + x);
+      for (int c = 0; c < 3; ++c) { mn[c] = std::min(mn[c], t[c]); mx[c] = std::max(mx[c], t[c]); }
+    }
+}
+
+void orc_equirect_to_cube_bounds(const float* hdr, int w, int h, int size, float ang, float* lo, float* hi, int64_t first, int64_t count) {
+  if (count < 0) count = 6LL * size * size - first;
+#pragma omp parallel for schedule(static)
+  for (int64_t t = first; t < first + count; ++t) {
+    int gz = (int)(t / ((int64_t)size * size)), gy = (int)((t / size) % size), gx = (int)(t % size);
+    float mn[3], mx[3];
+    range_min_max(hdr, w, equirect_pixel_range(texel_direction(gx, gy, gz, size), w, h, ang), mn, mx);
+    for (int c = 0; c < 3; ++c) { lo[4 * t + c] = mn[c]; hi[4 * t + c] = mx[c]; }
+    lo[4 * t + 3] = hi[4 * t + 3] = 1.0f;
+  }
+}
+
+void orc_irradiance_bounds(const float* hdr, int w, int h, int size, float ang, float* lo, float* hi, int64_t first, int64_t count) {
+  if (count < 0) count = 6LL * size * size - first;
+#pragma omp parallel for schedule(dynamic, 8)
+  for (int64_t t = first; t < first + count; ++t) {
+    int gz = (int)(t / ((int64_t)size * size)), gy = (int)((t / size) % size), gx = (int)(t % size);
+    V3 n = texel_direction(gx, gy, gz, size);
+    V3 up = {0, 1, 0};
+    V3 right = normalize(cross(up, n));
+    up = normalize(cross(n, right));
+    double sl[3] = {0, 0, 0}, sh[3] = {0, 0, 0};
+    const float delta = 0.025f;
+    int samples = 0;
+    for (float phi = 0.0f; phi < 2.0f * PI; phi += delta)
+      for (float theta = 0.0f; theta < 0.5f * PI; theta += delta) {
+        V3 ts = {std::sin(theta) * std::cos(phi), std::sin(theta) * std::sin(phi), std::cos(theta)};
+        V3 sv = add(add(mul(right, ts.x), mul(up, ts.y)), mul(n, ts.z));
+        float mn[3], mx[3];
+        range_min_max(hdr, w, equirect_pixel_range(sv, w, h, ang), mn, mx);
+        const float wgt = std::cos(theta) * std::sin(theta);
+        for (int c = 0; c < 3; ++c) { sl[c] += (double)mn[c] * wgt; sh[c] += (double)mx[c] * wgt; }
+        ++samples;
+      }
+    for (int c = 0; c < 3; ++c) { lo[4 * t + c] = (float)(PI * sl[c] / samples); hi[4 * t + c] = (float)(PI * sh[c] / samples); }
+    lo[4 * t + 3] = hi[4 * t + 3] = 1.0f;
+  }
+}
+
+void orc_prefilter_bounds(const float* chain, int w, int h, int levels, int size, float roughness, float ang, float* lo, float* hi,
+                          int64_t first, int64_t count) {
+  if (count < 0) count = 6LL * size * size - first;
+  const uint32_t SAMPLE_COUNT = 1024u;
+  std::vector<int64_t> level_off(levels);
+  for (int l = 0; l < levels; ++l) level_off[l] = orc_chain_offset(w, h, l);
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int64_t t = first; t < first + count; ++t) {
+    int gz = (int)(t / ((int64_t)size * size)), gy = (int)((t / size) % size), gx = (int)(t % size);
+    V3 N = texel_direction(gx, gy, gz, size), R = N, V = R;
+    double sl[3] = {0, 0, 0}, sh[3] = {0, 0, 0}, total_weight = 0;
+    for (uint32_t i = 0; i < SAMPLE_COUNT; ++i) {
+      float xi_x = (float)i / (float)SAMPLE_COUNT, xi_y = orc_radical_inverse(i);
+      V3 H = importance_sample_ggx(xi_x, xi_y, N, roughness);
+      V3 L = normalize(sub(mul(H, 2.0f * dot(V, H)), V));
+      float ndotl = std::max(dot(N, L), 0.0f);
+      if (!(ndotl > 0.0f)) continue;
+      float D = ggx_d(N, H, roughness);
+      float ndoth = std::max(dot(N, H), 0.0f), hdotv = std::max(dot(H, V), 0.0f);
+      float pdf = D * ndoth / (4.0f * hdotv) + 0.0001f;
+      float sa_texel = 4.0f * PI / (6.0f * 512.0f * 512.0f);
+      float sa_sample = 1.0f / ((float)SAMPLE_COUNT * pdf + 0.0001f);
+      float mip = roughness == 0.0f ? 0.0f : 0.5f * std::log2(sa_sample / sa_texel);
+      int m0 = (int)std::floor(mip);
+      float mix = mip - (float)m0;
+      int l0 = std::min(std::max(m0, 0), levels - 1), l1 = std::min(std::max(m0 + 1, 0), levels - 1);
+      float mn0[3], mx0[3], mn1[3], mx1[3];
+      range_min_max(chain + 4 * level_off[l0], level_dim(w, l0), equirect_pixel_range(L, level_dim(w, l0), level_dim(h, l0), ang), mn0, mx0);
+      range_min_max(chain + 4 * level_off[l1], level_dim(w, l1), equirect_pixel_range(L, level_dim(w, l1), level_dim(h, l1), ang), mn1, mx1);
+      for (int c = 0; c < 3; ++c) {
+        sl[c] += (double)ndotl * ((double)mn0[c] * (1.0 - mix) + (double)mn1[c] * mix);
+        sh[c] += (double)ndotl * ((double)mx0[c] * (1.0 - mix) + (double)mx1[c] * mix);
+      }
+      total_weight += ndotl;
+    }
+    for (int c = 0; c < 3; ++c) { lo[4 * t + c] = (float)(sl[c] / total_weight); hi[4 * t + c] = (float)(sh[c] / total_weight); }
+    lo[4 * t + 3] = hi[4 * t + 3] = 1.0f;
   }
 }
 

@@ -69,6 +69,12 @@ void orc_irradiance(const float* hdr, int w, int h, int size, float* out,
                     int64_t first, int64_t count);                             /* irradiancemap.wgsl */
 void orc_prefilter(const float* hdr_chain, int w, int h, int levels, int size, float roughness,
                    float* out, int64_t first, int64_t count);                  /* prefiltermap.wgsl */
+/* Test instrumentation (not part of the restated pipeline): per output texel the interval [lo, hi] of values reachable
+ * when every nearest-pixel lookup whose direction lies within `ang` radians of a pixel boundary may take either pixel. */
+void orc_equirect_to_cube_bounds(const float* hdr, int w, int h, int size, float ang, float* lo, float* hi, int64_t first, int64_t count);
+void orc_irradiance_bounds(const float* hdr, int w, int h, int size, float ang, float* lo, float* hi, int64_t first, int64_t count);
+void orc_prefilter_bounds(const float* hdr_chain, int w, int h, int levels, int size, float roughness, float ang, float* lo, float* hi,
+                          int64_t first, int64_t count);
 /* brdf.wgsl: out is [size][size][4] f32 before the rgba16float store; out_f16 (may be NULL)
  * receives the stored half bits.  Rows [row0,row0+rows). */
 void orc_brdf_lut(int size, float* out_f32, uint16_t* out_f16, int row0, int rows);
@@ -126,6 +132,10 @@ void orc_shade(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int 
 /* Convenience: raster + shade. */
 void orc_draw_frame(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int y0, int y1,
                     uint8_t* rgba8, uint32_t* vis_or_null);
+/* Test instrumentation: the same frame plus, per pixel, how close any discrete sampling decision of the pixel (mip level
+ * of a "nearest" mipmap filter, min / mag switch, texel of a "nearest" filter) was to its switching point; see frame.cpp. */
+void orc_draw_frame_margins(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int y0, int y1,
+                            uint8_t* rgba8, uint32_t* vis, float* margin);
 
 /* Samplers exposed for unit tests. */
 void orc_sample_cube(const float* chain, int size, int levels, const float* dir3, float lod, float* rgba_out);

@@ -71,6 +71,10 @@ def load():
         "orc_equirect_to_cube": (None, [P, C.c_int, C.c_int, C.c_int, P, I64, I64]),
         "orc_irradiance": (None, [P, C.c_int, C.c_int, C.c_int, P, I64, I64]),
         "orc_prefilter": (None, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, P, I64, I64]),
+        "orc_equirect_to_cube_bounds": (None, [P, C.c_int, C.c_int, C.c_int, C.c_float, P, P, I64, I64]),
+        "orc_irradiance_bounds": (None, [P, C.c_int, C.c_int, C.c_int, C.c_float, P, P, I64, I64]),
+        "orc_prefilter_bounds": (None, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, P, P, I64, I64]),
+        "orc_draw_frame_margins": (None, [C.POINTER(Scene), C.POINTER(FrameUniforms), C.c_int, C.c_int, C.c_int, C.c_int, P, P, P]),
         "orc_brdf_lut": (None, [C.c_int, P, P, C.c_int, C.c_int]),
         "orc_radical_inverse": (C.c_float, [C.c_uint32]),
         "orc_irradiance_trip_counts": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -145,6 +149,30 @@ def prefilter_level(chain, w, h, levels, size, roughness, first=0, count=-1):
     out = np.zeros((6, size, size, 4), dtype=np.float32)
     lib.orc_prefilter(ptr(chain), w, h, levels, size, float(roughness), ptr(out), first, count)
     return out
+
+
+BOUNDARY_SLACK = 5e-7   # radians: how far a lookup direction / the inverse trigonometric functions may differ between implementations
+
+
+def equirect_to_cube_bounds(hdr, w, h, size, ang=BOUNDARY_SLACK, first=0, count=-1):
+    lib = load()
+    lo, hi = np.zeros((6, size, size, 4), dtype=np.float32), np.zeros((6, size, size, 4), dtype=np.float32)
+    lib.orc_equirect_to_cube_bounds(ptr(hdr), w, h, size, ang, ptr(lo), ptr(hi), first, count)
+    return lo, hi
+
+
+def irradiance_bounds(hdr, w, h, size, ang=BOUNDARY_SLACK, first=0, count=-1):
+    lib = load()
+    lo, hi = np.zeros((6, size, size, 4), dtype=np.float32), np.zeros((6, size, size, 4), dtype=np.float32)
+    lib.orc_irradiance_bounds(ptr(hdr), w, h, size, ang, ptr(lo), ptr(hi), first, count)
+    return lo, hi
+
+
+def prefilter_level_bounds(chain, w, h, levels, size, roughness, ang=BOUNDARY_SLACK, first=0, count=-1):
+    lib = load()
+    lo, hi = np.zeros((6, size, size, 4), dtype=np.float32), np.zeros((6, size, size, 4), dtype=np.float32)
+    lib.orc_prefilter_bounds(ptr(chain), w, h, levels, size, float(roughness), ang, ptr(lo), ptr(hi), first, count)
+    return lo, hi
 
 
 def brdf_lut(size, row0=0, rows=-1):

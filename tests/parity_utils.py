@@ -98,6 +98,30 @@ class OracleScene:
         self.lib.orc_draw_frame(C.byref(sc), C.byref(u), W, H, y0, y1, ob.ptr(rgba), ob.ptr(vis))
         return rgba, vis
 
+    def draw_with_margins(self, uniforms, W, H, y0=0, y1=None):
+        """The frame plus, per pixel, how close any discrete sampling decision (mip level, min / mag switch, nearest
+        texel) came to its switching point (oracle/frame.cpp, note_margin)."""
+        y1 = H if y1 is None else y1
+        sc = self.c_scene()
+        u = copy_uniforms(uniforms, ob.FrameUniforms)
+        rgba = np.zeros((y1 - y0, W, 4), dtype=np.uint8)
+        vis = np.zeros(vis_shape(uniforms, y1 - y0, W), dtype=np.uint32)
+        margin = np.zeros((y1 - y0, W), dtype=np.float32)
+        self.lib.orc_draw_frame_margins(C.byref(sc), C.byref(u), W, H, y0, y1, ob.ptr(rgba), ob.ptr(vis), ob.ptr(margin))
+        return rgba, vis, margin
+
+    def map_bounds(self):
+        """Reachable intervals of the three nearest-pixel cube generators (oracle/ibl.cpp, *_bounds)."""
+        if getattr(self, "_bounds", None) is None:
+            h = self.hdr
+            pre = []
+            for m in range(self.pre_mips):
+                rough = np.float32(m / (self.pre_mips - 1)) if self.pre_mips > 1 else np.float32(0.0)
+                pre.append(ob.prefilter_level_bounds(self.hdr_chain, h.width, h.height, self.hdr_levels, max(1, self.pre_size >> m), rough))
+            self._bounds = {"sky": ob.equirect_to_cube_bounds(self.hdr_data, h.width, h.height, self.sky_size),
+                            "irr": ob.irradiance_bounds(self.hdr_data, h.width, h.height, self.irr_size), "pre": pre}
+        return self._bounds
+
     def raster(self, uniforms, W, H, y0=0, y1=None):
         y1 = H if y1 is None else y1
         sc = self.c_scene()
@@ -150,6 +174,9 @@ class SmallScene:
 
     def render_oracle(self, y0=0, y1=None):
         return self.oracle.draw(self.uniforms(), self.width, self.height, y0, y1)
+
+    def render_oracle_with_margins(self, y0=0, y1=None):
+        return self.oracle.draw_with_margins(self.uniforms(), self.width, self.height, y0, y1)
 
 
 def psnr(a, b):

@@ -3,8 +3,14 @@
 Tolerances are the ones the task states: visibility buffer identical on >= 99.9 % of pixels
 (it is bit-exact here), shaded 8-bit output within 2/255 per channel on >= 99.9 % of pixels with
 PSNR >= 45 dB, IBL maps within 1e-3 relative error.  The relative error of a texel is taken against
-max(|reference|, 1e-3 * mean of the map) and a 0.1 % share of texels may exceed 1e-3 — nearest-texel
-source lookups flip when atan2/asin differ by an ulp between libm and the GPU's math library.
+max(|reference|, 1e-3 * mean of the map).
+
+The cube generators read NEAREST equirect pixels, so a sample whose coordinate sits within rounding distance of
+a pixel boundary may land on the neighbouring pixel when atan2 / asin differ by an ulp between libm and the GPU's
+math library, and next to the 5 000-nit sun one such flip moves a texel by far more than 1e-3.  Such texels are
+not waved through by a loose bound: the oracle also computes, per texel, the interval of values reachable when
+every sample within 5e-7 rad of a pixel boundary may take either pixel (oracle/ibl.cpp, *_bounds), EVERY texel must
+lie within 1e-3 of that interval, and the share of texels that needed the interval is bounded and printed.
 """
 import ctypes as C
 import os
@@ -27,11 +33,52 @@ def rel_err(got, ref):
     return np.abs(got - ref) / np.maximum(np.abs(ref), floor)
 
 
-def assert_map_close(got, ref, name, share=1e-3, worst=0.5):
-    e = rel_err(got[..., :3], ref[..., :3])
-    assert (e > 1e-3).mean() <= share, f"{name}: {(e > 1e-3).mean():.5f} of texels beyond 1e-3 (max {e.max():.3e})"
-    assert e.max() < worst, f"{name}: max relative error {e.max():.3e}"
+def assert_map_close(got, ref, name, bounds, share=1e-3, tol=1e-3):
+    """Every texel within `tol` of the oracle's value, or - for the texels with a sample on a pixel boundary - within
+    `tol` of the interval of values reachable by resolving those samples either way; at most `share` of the texels may
+    need the interval."""
+    lo, hi = bounds
+    g, r = got[..., :3].astype(np.float64), ref[..., :3].astype(np.float64)
+    floor = 1e-3 * np.abs(r).mean()
+    scale = np.maximum(np.abs(r), floor)
+    nominal = np.abs(g - r) / scale
+    outside = np.maximum(np.maximum(lo[..., :3].astype(np.float64) - g, g - hi[..., :3].astype(np.float64)), 0.0) / scale
+    flips = int((nominal > tol).any(-1).sum())
+    n = int(np.prod(got.shape[:-1]))
+    print(f"{name}: {flips} of {n} texels beyond {tol:g} of the nominal value (max {nominal.max():.3e}), max distance to the reachable interval {outside.max():.3e}")
+    assert outside.max() <= tol, f"{name}: a texel is {outside.max():.3e} away from every value its samples can reach"
+    assert flips <= share * n + 1, f"{name}: {flips / n:.5f} of texels beyond {tol:g} (allowed {share:g})"
     assert (got[..., 3] == 1.0).all(), name
+
+
+def assert_texel_copies(got, ref, bounds, name, share=1e-4):
+    """equirect -> cube copies texels: a texel either is the oracle's source pixel or, when its direction sits on a
+    pixel boundary, one of the neighbouring candidates."""
+    lo, hi = bounds
+    same = (got == ref).all(-1)
+    inside = ((got[..., :3] >= lo[..., :3]) & (got[..., :3] <= hi[..., :3])).all(-1)
+    print(f"{name}: {int((~same).sum())} of {same.size} texels copied from a neighbouring source pixel")
+    assert inside.all(), f"{name}: {int((~inside).sum())} texels are no copy of any candidate pixel"
+    assert (~same).mean() <= share, f"{name}: {(~same).mean():.6f} of texels differ"
+
+
+# How far the level-of-detail of a lookup may differ between two correct implementations: lambda = log2 of the length
+# of uv DIFFERENCES between neighbouring pixels; the uv themselves agree to ~1e-7, their differences (~1e-3) therefore
+# only to ~1e-4 relative, which is 1.5e-4 in lambda.  Ten times that.
+LOD_SLACK = 2e-3
+
+
+def assert_only_fragile_pixels_differ(rgba, ref_rgba, margin, name, share=0.005):
+    """Every pixel beyond 2/255 must be one where the oracle itself took a discrete sampling decision (mip level of a
+    "nearest" mipmap filter, min / mag switch, nearest texel) within LOD_SLACK of its switching point, i.e. where
+    last-bit differences in the derivatives legitimately select the other level or texel; and they must be few."""
+    d = np.abs(rgba.astype(np.int32) - ref_rgba.astype(np.int32)).max(-1)
+    off = d > 2
+    n_off = int(off.sum())
+    print(f"{name}: {n_off} of {d.size} pixels beyond 2/255 (max {int(d.max())}), all with a decision margin below {LOD_SLACK:g}: "
+          f"{bool((margin[off] < LOD_SLACK).all())}")
+    assert (margin[off] < LOD_SLACK).all(), f"{name}: a pixel differs by {int(d[off & (margin >= LOD_SLACK)].max())}/255 with no sampling decision near its switching point"
+    assert n_off <= share * d.size + 1, f"{name}: {n_off} pixels beyond 2/255"
 
 
 def assert_frame_close(rgba, ref_rgba, vis, ref_vis, name=""):
@@ -61,17 +108,17 @@ def refsize():
 
 
 def test_ibl_maps_match_oracle(small):
-    lib, r, m = small.pkg._lib, small.renderer, small.oracle.maps()
+    lib, r, m, b = small.pkg._lib, small.renderer, small.oracle.maps(), small.oracle.map_bounds()
     sky = r.download_map(lib.MAP_SKYBOX)
-    assert (sky == m["sky"]).all(axis=-1).mean() >= 0.9999           # texel copies: exact unless the source pixel flips
+    assert_texel_copies(sky, m["sky"], b["sky"], "skybox cube")     # texel copies: exact unless the source pixel flips
     irr = r.download_map(lib.MAP_IRRADIANCE)
-    assert_map_close(irr, m["irr"], "irradiance", share=2e-3)
+    assert_map_close(irr, m["irr"], "irradiance", b["irr"], share=2e-3)
     # the centre texel of the +-Y faces: the shader's tangent frame is 0/0 there and every tap reads equirect pixel (0, 0)
     for face in (2, 3):
         np.testing.assert_allclose(irr[face, 8, 8, :3], m["irr"][face, 8, 8, :3], rtol=1e-3)
         np.testing.assert_allclose(irr[face, 8, 8, :3], small.oracle.hdr_data.reshape(-1, 4)[0, :3] * m["irr"][face, 8, 8, 0] / small.oracle.hdr_data[0], rtol=1e-5)
     for lvl in range(5):
-        assert_map_close(r.download_map(lib.MAP_PREFILTER, lvl), m["pre"][lvl], f"prefilter level {lvl}")
+        assert_map_close(r.download_map(lib.MAP_PREFILTER, lvl), m["pre"][lvl], f"prefilter level {lvl}", b["pre"][lvl])
     lut = r.download_map(lib.MAP_BRDF_LUT).view(np.float16).astype(np.float32)
     ref = m["lut"].view(np.float16).astype(np.float32)
     assert (np.isnan(lut) == np.isnan(ref)).all()
@@ -88,11 +135,11 @@ def test_ibl_maps_from_an_odd_sized_hdr():
     prefilter then takes its general path for the coarser of a sample's two source levels."""
     s = pu.SmallScene.build(width=64, height=36, hdr_size=(2200, 1100), sky_size=32, pre_size=32, pre_mips=4, lut_size=16, irr_size=4)
     try:
-        lib, r, m = s.pkg._lib, s.renderer, s.oracle.maps()
-        assert (r.download_map(lib.MAP_SKYBOX) == m["sky"]).all(axis=-1).mean() >= 0.999
-        assert_map_close(r.download_map(lib.MAP_IRRADIANCE), m["irr"], "irradiance", share=5e-3)
+        lib, r, m, b = s.pkg._lib, s.renderer, s.oracle.maps(), s.oracle.map_bounds()
+        assert_texel_copies(r.download_map(lib.MAP_SKYBOX), m["sky"], b["sky"], "skybox cube (odd HDR)", share=1e-3)
+        assert_map_close(r.download_map(lib.MAP_IRRADIANCE), m["irr"], "irradiance", b["irr"], share=5e-3)
         for lvl in range(4):
-            assert_map_close(r.download_map(lib.MAP_PREFILTER, lvl), m["pre"][lvl], f"prefilter level {lvl}", share=2e-3)
+            assert_map_close(r.download_map(lib.MAP_PREFILTER, lvl), m["pre"][lvl], f"prefilter level {lvl}", b["pre"][lvl], share=2e-3)
     finally:
         s.renderer.close()
 
@@ -103,6 +150,79 @@ def test_hdr_mip_chain_matches_oracle(small):
         got = r.download_map(lib.MAP_HDR, lvl)
         want = ob.chain_level(o.hdr_chain, o.hdr.width, o.hdr.height, lvl)
         np.testing.assert_allclose(got, want, rtol=2e-6)
+
+
+def test_material_mip_chains_are_byte_exact(small):
+    """Every level of the five 2048^2 material textures as the device holds it against the oracle's chain: the 2x2 box
+    average rounded to 8 bits at every level, in linear light with an sRGB re-encode per level for the two
+    rgba8unorm-srgb textures (renderer.ts:647, :697), straight for the three rgba8unorm ones."""
+    lib, r, o = small.pkg._lib, small.renderer, small.oracle
+    for slot in range(5):
+        img = o.images[slot]
+        h0, w0 = img.shape[:2]
+        assert o.levels[slot] == 12 and (w0, h0) == (2048, 2048)
+        for level in range(o.levels[slot]):
+            w, h = C.c_int32(), C.c_int32()
+            lib.check(r._ctx, r._lib.pbr_debug_texture_level(r._ctx, slot, level, None, 0, C.byref(w), C.byref(h)))
+            assert (w.value, h.value) == (max(1, w0 >> level), max(1, h0 >> level))
+            got = np.zeros((h.value, w.value, 4), np.uint8)
+            lib.check(r._ctx, r._lib.pbr_debug_texture_level(r._ctx, slot, level, ob.ptr(got), got.nbytes, None, None))
+            want = ob.chain_level(o.chains[slot], w0, h0, level)
+            assert (got == want).all(), (slot, level, int((got != want).sum()))
+    assert r._lib.pbr_debug_texture_level(r._ctx, 0, 12, None, 0, None, None) == lib.PBR_E_ARG
+    assert r._lib.pbr_debug_texture_level(r._ctx, 5, 0, None, 0, None, None) == lib.PBR_E_ARG
+
+
+def test_rectangular_and_odd_mip_chains_are_byte_exact():
+    """Textures that are not square powers of two (a 300 x 77 sRGB and a 5 x 64 unorm image): level sizes
+    max(1, floor(d / 2)) (renderer.ts:1213-1214), footprints clamped at the edges."""
+    pkg = pu._pkg()
+    lib = pkg._lib
+    rng = np.random.default_rng(11)
+    ctx = C.c_void_p()
+    lib.check(None, lib.load().pbr_create(0, C.byref(ctx)))
+    try:
+        for slot, (w, h), srgb in ((0, (300, 77), True), (2, (5, 64), False), (3, (1, 1), True)):
+            img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+            lib.check(ctx, lib.load().pbr_upload_texture(ctx, slot, ob.ptr(img), w, h, 1 if srgb else 0, 1))
+            chain, levels = ob.mip_chain_rgba8(img, srgb)
+            for level in range(levels):
+                lw, lh = max(1, w >> level), max(1, h >> level)
+                got = np.zeros((lh, lw, 4), np.uint8)
+                lib.check(ctx, lib.load().pbr_debug_texture_level(ctx, slot, level, ob.ptr(got), got.nbytes, None, None))
+                assert (got == ob.chain_level(chain, w, h, level)).all(), (slot, level)
+            assert lib.load().pbr_debug_texture_level(ctx, slot, levels, None, 0, None, None) == lib.PBR_E_ARG
+    finally:
+        lib.load().pbr_destroy(ctx)
+
+
+def test_reference_default_skybox_size():
+    """The reference's own skybox cube, 1440^2 (renderer.ts:980-985, 90 x 90 x 6 workgroups of 16 x 16, :1436): no power
+    of two, so the bordered copy and the skybox lookup run with odd strides.  The cube against the oracle's, and an
+    all-sky band plus a band through the helmet of a frame that samples it."""
+    s = pu.SmallScene.build(width=640, height=360, hdr_size=(4096, 2048), sky_size=1440, pre_size=32, pre_mips=4, lut_size=64, irr_size=8)
+    try:
+        lib, r = s.pkg._lib, s.renderer
+        sky = r.download_map(lib.MAP_SKYBOX)
+        assert sky.shape == (6, 1440, 1440, 4)
+        ref = ob.equirect_to_cube(s.oracle.hdr_data, 4096, 2048, 1440)
+        bounds = ob.equirect_to_cube_bounds(s.oracle.hdr_data, 4096, 2048, 1440)
+        assert_texel_copies(sky, ref, bounds, "1440^2 skybox cube")
+        s.oracle._maps = None
+        rgba, vis = s.render_gpu()
+        for y0, y1 in ((0, 24), (168, 192)):
+            orgba, ovis = s.render_oracle(y0, y1)
+            assert (vis[y0:y1] == ovis).all()
+            assert_frame_close(rgba[y0:y1], orgba, vis[y0:y1], ovis, f"1440^2 skybox rows {y0}..{y1}")
+        assert (vis[:24] == 0).all() and (vis[168:192] > 0).any()
+        # a view along a cube edge and into a corner, where the lookups cross faces through the border texels
+        r.camera.update_camera_rotation(-450.0, 350.0)
+        rgba, vis = s.render_gpu()
+        orgba, ovis = s.render_oracle(0, 40)
+        assert (vis[:40] == ovis).all()
+        assert_frame_close(rgba[:40], orgba, vis[:40], ovis, "1440^2 skybox, turned view")
+    finally:
+        s.renderer.close()
 
 
 def test_vertex_stage_is_bit_exact(small):
@@ -196,9 +316,11 @@ def test_near_plane_clipping_matches_oracle(small):
     small.renderer.camera = small.pkg.Camera()
 
 
-@pytest.mark.parametrize("sampler_index,mipmaps", [(15, False), (0, True), (5, True), (10, True), (7, True), (11, False), (12, True), (3, True)])
+@pytest.mark.parametrize("sampler_index,mipmaps", [(15, False), (0, True), (5, True), (10, True), (7, True), (11, False), (12, True), (3, True),
+                                                   (1, True), (2, False), (4, True), (6, True), (8, True), (9, False), (13, True), (14, True), (0, False)])
 def test_sampler_matrix_matches_oracle(small, sampler_index, mipmaps):
-    """The 16 material samplers of renderer.ts:822-829 and the mipmap toggle of renderer.ts:1977."""
+    """All 16 material samplers of renderer.ts:822-829 (index 15 with mipmaps is the default view's test) and the mipmap
+    toggle of renderer.ts:1977."""
     r = small.renderer
     r.camera = small.pkg.Camera()
     r.texture_options.update(addressModeU="repeat" if sampler_index & 1 else "clamp-to-edge", addressModeV="repeat" if sampler_index & 2 else "clamp-to-edge",
@@ -206,9 +328,10 @@ def test_sampler_matrix_matches_oracle(small, sampler_index, mipmaps):
     try:
         assert r.frame_uniforms().sampler_index == sampler_index
         rgba, vis = small.render_gpu()
-        orgba, ovis = small.render_oracle()
+        orgba, ovis, margin = small.render_oracle_with_margins()
         assert (vis == ovis).all()
         assert_frame_close(rgba, orgba, vis, ovis, f"sampler {sampler_index} mips {mipmaps}")
+        assert_only_fragile_pixels_differ(rgba, orgba, margin, f"sampler {sampler_index} mips {mipmaps}", share=0.001)
     finally:
         r.texture_options.update(addressModeU="repeat", addressModeV="repeat", magFilter="linear", minFilter="linear", mipmaps=True)
 
@@ -276,10 +399,9 @@ def test_ragged_target_sizes_match_oracle(small, size):
         for msaa in (False, True):
             r.msaa_options["enable"] = msaa
             rgba, vis = small.render_gpu()
-            orgba, ovis = small.render_oracle()
+            orgba, ovis, margin = small.render_oracle_with_margins()
             assert vis.shape == ovis.shape and (vis == ovis).all(), (size, msaa)
-            d = np.abs(rgba.astype(np.int32) - orgba.astype(np.int32)).max(-1)
-            assert (d <= 2).mean() >= 0.995 and d.max() <= 8, (size, msaa, d.max(), (d <= 2).mean())
+            assert_only_fragile_pixels_differ(rgba, orgba, margin, f"{size} msaa={msaa}")
             assert (rgba[..., 3] == 255).all()
     finally:
         r.msaa_options["enable"] = False
@@ -319,10 +441,10 @@ def test_strips_equal_full_frame(small):
 
 def test_reference_sizes_720p(refsize):
     """The 1280x720 single frame with the reference's IBL sizes."""
-    lib, r, m = refsize.pkg._lib, refsize.renderer, refsize.oracle.maps()
-    assert_map_close(r.download_map(lib.MAP_IRRADIANCE), m["irr"], "irradiance 32", share=2e-3)
+    lib, r, m, b = refsize.pkg._lib, refsize.renderer, refsize.oracle.maps(), refsize.oracle.map_bounds()
+    assert_map_close(r.download_map(lib.MAP_IRRADIANCE), m["irr"], "irradiance 32", b["irr"], share=2e-3)
     for lvl in range(5):
-        assert_map_close(r.download_map(lib.MAP_PREFILTER, lvl), m["pre"][lvl], f"prefilter 128 level {lvl}")
+        assert_map_close(r.download_map(lib.MAP_PREFILTER, lvl), m["pre"][lvl], f"prefilter 128 level {lvl}", b["pre"][lvl])
     lut = r.download_map(lib.MAP_BRDF_LUT).view(np.float16).astype(np.float32)
     ref = m["lut"].view(np.float16).astype(np.float32)
     assert (np.isnan(lut) == np.isnan(ref)).all()
@@ -462,11 +584,12 @@ def test_large_prefilter_spot_checks():
             n = 6 * s * s
             count = min(256, n)
             for first in sorted(set(int(x) for x in rng.integers(0, n - count + 1, size=3))):
-                ref = ob.prefilter_level(chain, hdr.width, hdr.height, levels, s, np.float32(m / (mips - 1)), first, count)
-                a = got.reshape(-1, 4)[first:first + count]
-                b = ref.reshape(-1, 4)[first:first + count]
-                e = rel_err(a[:, :3], b[:, :3])
-                assert (e > 1e-3).mean() <= 0.01 and e.max() < 0.5, (m, first, e.max())
+                rough = np.float32(m / (mips - 1))
+                ref = ob.prefilter_level(chain, hdr.width, hdr.height, levels, s, rough, first, count)
+                lo, hi = ob.prefilter_level_bounds(chain, hdr.width, hdr.height, levels, s, rough, first=first, count=count)
+                cut = slice(first, first + count)
+                assert_map_close(got.reshape(-1, 4)[cut], ref.reshape(-1, 4)[cut], f"2048^2 level {m} texels {first}..{first + count}",
+                                 (lo.reshape(-1, 4)[cut], hi.reshape(-1, 4)[cut]), share=0.01)
     finally:
         r.close()
 
@@ -610,10 +733,11 @@ def test_gpu_matches_golden_vectors():
     s = pu.SmallScene.build(**mg.FRAME_CFG)
     lib, r = s.pkg._lib, s.renderer
     try:
-        assert (r.download_map(lib.MAP_SKYBOX) == gold_ibl["sky"]).all(-1).mean() >= 0.999
-        assert_map_close(r.download_map(lib.MAP_IRRADIANCE), gold_ibl["irr"], "golden irradiance", share=0.02)
+        b = s.oracle.map_bounds()        # the intervals come from the oracle that also made the golden vectors
+        assert_texel_copies(r.download_map(lib.MAP_SKYBOX), gold_ibl["sky"], b["sky"], "golden skybox cube", share=1e-3)
+        assert_map_close(r.download_map(lib.MAP_IRRADIANCE), gold_ibl["irr"], "golden irradiance", b["irr"], share=0.02)
         for l in range(3):
-            assert_map_close(r.download_map(lib.MAP_PREFILTER, l), gold_ibl[f"pre{l}"], f"golden prefilter {l}", share=0.01)
+            assert_map_close(r.download_map(lib.MAP_PREFILTER, l), gold_ibl[f"pre{l}"], f"golden prefilter {l}", b["pre"][l], share=0.01)
         for name, moves in mg.VIEWS.items():
             r.camera = s.pkg.Camera()
             mg.apply_view(r.camera, moves)

@@ -43,7 +43,10 @@ PBR_DEV float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : powf
 PBR_DEV float linear_to_srgb(float c) { return c <= 0.0031308f ? c * 12.92f : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f; }
 
 // Footprint of the one bilinear tap mipmap.wgsl takes at a destination texel centre (clamp-to-edge).
+// (every product and sum of the mip filters is rounded on its own, as written: for level sizes that do not halve
+// exactly the weights are no powers of two, and a fused multiply-add would move a byte on a rounding boundary)
 PBR_DEV void mip_axis(int dst_i, int dst_n, int src_n, int& i0, int& i1, float& a) {
+#pragma clang fp contract(off)
   float u = ((float)dst_i + 0.5f) / (float)dst_n;
   float t = u * (float)src_n - 0.5f;
   float fl = floorf(t);
@@ -54,6 +57,7 @@ PBR_DEV void mip_axis(int dst_i, int dst_n, int src_n, int& i0, int& i1, float& 
 }
 
 __global__ void __launch_bounds__(256) mip_rgba32f_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int sw, int sh, int dw, int dh) {
+#pragma clang fp contract(off)
   int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
   int x0, x1, y0, y1; float a, b;
@@ -69,7 +73,14 @@ __global__ void __launch_bounds__(256) mip_rgba32f_kernel(const float4* __restri
   dst[(size_t)y * dw + x] = o;
 }
 
-__global__ void __launch_bounds__(256) mip_rgba8_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int sw, int sh, int dw, int dh, int srgb) {
+__global__ void __launch_bounds__(256) mip_rgba8_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, int sw, int sh, int dw, int dh, int srgb,
+                                                        const float* __restrict__ srgb_tables) {
+#pragma clang fp contract(off)
+  // decode table and store thresholds of the 8-bit sRGB codes (host-made: the same numbers on every implementation)
+  __shared__ float s_dec[256], s_thr[257];
+  for (int i = threadIdx.x; i < 256; i += 256) s_dec[i] = srgb_tables[i];
+  for (int i = threadIdx.x; i < 257; i += 256) s_thr[i] = srgb_tables[256 + i];
+  __syncthreads();
   int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
   int x0, x1, y0, y1; float a, b;
@@ -81,13 +92,19 @@ __global__ void __launch_bounds__(256) mip_rgba8_kernel(const uint32_t* __restri
   uint32_t out = 0;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
-    float s00 = (float)((t00 >> (8 * c)) & 255u) / 255.0f, s10 = (float)((t10 >> (8 * c)) & 255u) / 255.0f;
-    float s01 = (float)((t01 >> (8 * c)) & 255u) / 255.0f, s11 = (float)((t11 >> (8 * c)) & 255u) / 255.0f;
+    const uint32_t b00 = (t00 >> (8 * c)) & 255u, b10 = (t10 >> (8 * c)) & 255u, b01 = (t01 >> (8 * c)) & 255u, b11 = (t11 >> (8 * c)) & 255u;
     const bool enc = srgb && c < 3;   // the average is taken in linear light and re-encoded at every level
-    if (enc) { s00 = srgb_to_linear(s00); s10 = srgb_to_linear(s10); s01 = srgb_to_linear(s01); s11 = srgb_to_linear(s11); }
-    float v = ((s00 * w00 + s10 * w10) + s01 * w01) + s11 * w11;
-    if (enc) v = linear_to_srgb(v);
-    out |= to_unorm8(v) << (8 * c);
+    if (enc) {
+      const float v = ((s_dec[b00] * w00 + s_dec[b10] * w10) + s_dec[b01] * w01) + s_dec[b11] * w11;
+      // exactly rounded store: the formula proposes a code, the thresholds decide (code k for thr[k] <= v < thr[k + 1])
+      int k = (int)to_unorm8(linear_to_srgb(v));
+      while (k < 255 && v >= s_thr[k + 1]) ++k;
+      while (k > 0 && !(v >= s_thr[k])) --k;
+      out |= (uint32_t)k << (8 * c);
+    } else {
+      const float v = (((float)b00 / 255.0f * w00 + (float)b10 / 255.0f * w10) + (float)b01 / 255.0f * w01) + (float)b11 / 255.0f * w11;
+      out |= to_unorm8(v) << (8 * c);
+    }
   }
   dst[tex8_block_offset(x, y, dw)] = out;
 }
@@ -288,12 +305,13 @@ void launch_build_mips_rgba32f(hipStream_t s, float4* chain, const uint32_t* off
   }
 }
 
-void launch_build_mips_rgba8(hipStream_t s, const uint32_t* linear_level0, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb) {
+void launch_build_mips_rgba8(hipStream_t s, const uint32_t* linear_level0, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb,
+                             const float* srgb_tables) {
   hipLaunchKernelGGL(block_rgba8_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, s, linear_level0, chain + off[0], w, h);
   for (int l = 1; l < levels; ++l) {
     int sw = std::max(1, w >> (l - 1)), sh = std::max(1, h >> (l - 1)), dw = std::max(1, w >> l), dh = std::max(1, h >> l);
     dim3 grid((dw + 63) / 64, (dh + 3) / 4);
-    hipLaunchKernelGGL(mip_rgba8_kernel, grid, dim3(256), 0, s, chain + off[l - 1], chain + off[l], sw, sh, dw, dh, srgb);
+    hipLaunchKernelGGL(mip_rgba8_kernel, grid, dim3(256), 0, s, chain + off[l - 1], chain + off[l], sw, sh, dw, dh, srgb, srgb_tables);
   }
 }
 

@@ -588,8 +588,21 @@ int pbr_create(int device_ordinal, PbrContext** ctx_out) {
   if ((e = hipMalloc(&c->d_samples, sizeof(PrefilterSample) * PBR_PREFILTER_SAMPLES * PBR_MAX_LEVELS)) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&c->d_irr_tables, sizeof(float) * 2 * (512 + 128))) != hipSuccess) return bail("hipMalloc", e);
   {
-    float lut[256];   // sRGB transfer function of the rgba8unorm-srgb formats (renderer.ts:647, :697)
+    // sRGB transfer function of the rgba8unorm-srgb formats (renderer.ts:647, :697): decode table [0, 256), and from 256
+    // on the store thresholds of the mip generator: code k is stored for T[k] <= v < T[k + 1], T[k] = the linear value
+    // whose encoding is k - 1/2, from double precision, rounded up to the next float (the exactly rounded store; the
+    // device's powf only proposes a candidate)
+    float lut[256 + 257];
     for (int i = 0; i < 256; ++i) { float v = (float)i / 255.0f; lut[i] = v <= 0.04045f ? v / 12.92f : std::pow((v + 0.055f) / 1.055f, 2.4f); }
+    lut[256] = 0.0f;
+    for (int k = 1; k <= 255; ++k) {
+      const double cc = ((double)k - 0.5) / 255.0;
+      const double lin = cc <= 0.04045 ? cc / 12.92 : std::pow((cc + 0.055) / 1.055, 2.4);
+      float f = (float)lin;
+      if ((double)f < lin) f = std::nextafterf(f, 2.0f);
+      lut[256 + k] = f;
+    }
+    lut[256 + 256] = 3.0e38f;
     if ((e = hipMalloc(&box->priv.d_srgb_lut, sizeof lut)) != hipSuccess) return bail("hipMalloc", e);
     if ((e = hipMemcpy(box->priv.d_srgb_lut, lut, sizeof lut, hipMemcpyHostToDevice)) != hipSuccess) return bail("hipMemcpy", e);
   }
@@ -730,7 +743,7 @@ int pbr_upload_texture(PbrContext* c, int slot, const uint8_t* rgba8, int32_t w,
   uint32_t* staging = nullptr;   // the row-major image, re-laid into blocks on the device
   HIP_TRY(c, hipMalloc(&staging, (size_t)w * h * 4));
   hipError_t up = hipMemcpyAsync(staging, rgba8, (size_t)w * h * 4, hipMemcpyHostToDevice, c->stream);
-  if (up == hipSuccess) launch_build_mips_rgba8(c->stream, staging, c->d_tex[slot], t.off, w, h, t.levels, t.srgb);
+  if (up == hipSuccess) launch_build_mips_rgba8(c->stream, staging, c->d_tex[slot], t.off, w, h, t.levels, t.srgb, priv_of(c)->d_srgb_lut);
   if (up == hipSuccess) up = hipStreamSynchronize(c->stream);
   (void)hipFree(staging);
   HIP_TRY(c, up);
@@ -1067,6 +1080,29 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
     if (world) { world[3 * i] = host[i].world_u.x; world[3 * i + 1] = host[i].world_u.y; world[3 * i + 2] = host[i].world_u.z; }
     if (normal) { normal[3 * i] = host[i].nrm_v.x; normal[3 * i + 1] = host[i].nrm_v.y; normal[3 * i + 2] = host[i].nrm_v.z; }
   }
+  return PBR_OK;
+}
+
+int pbr_debug_texture_level(PbrContext* c, int slot, int32_t level, uint8_t* rgba8_out, size_t out_bytes, int32_t* w_out, int32_t* h_out) {
+  if (!c) return PBR_E_ARG;
+  if (c->parent) return fail(c, PBR_E_STATE, "a forked context draws the scene of the context it was forked from and cannot change or read it back");
+  if (slot < 0 || slot > 4) return fail(c, PBR_E_ARG, "texture slot %d out of range", slot);
+  if (!c->d_tex[slot]) return fail(c, PBR_E_STATE, "material texture slot %d not uploaded", slot);
+  const DevTex8& t = c->tex[slot];
+  if (level < 0 || level >= t.levels) return fail(c, PBR_E_ARG, "level %d out of range (0..%d)", level, t.levels - 1);
+  const int w = std::max(1, t.w >> level), h = std::max(1, t.h >> level);
+  if (w_out) *w_out = w;
+  if (h_out) *h_out = h;
+  if (!rgba8_out) return PBR_OK;   // size query
+  if (out_bytes < (size_t)w * h * 4) return fail(c, PBR_E_ARG, "output buffer holds %zu bytes, level needs %zu", out_bytes, (size_t)w * h * 4);
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // the level is stored in blocks of 8 x 4 texels on the device; undo that on the host
+  std::vector<uint32_t> blocked(tex8_level_texels(w, h));
+  HIP_TRY(c, hipMemcpy(blocked.data(), t.base + t.off[level], blocked.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  uint32_t* out = reinterpret_cast<uint32_t*>(rgba8_out);
+  for (int y = 0; y < h; ++y)
+    for (int x = 0; x < w; ++x) { const uint32_t v = blocked[tex8_block_offset(x, y, w)]; std::memcpy(out + (size_t)y * w + x, &v, 4); }
   return PBR_OK;
 }
 

@@ -165,7 +165,9 @@ struct PbrContext {
 // ---- kernel launchers (defined in the .hip files) ----
 void launch_build_mips_rgba32f(hipStream_t s, float4* chain, const uint32_t* off, int w, int h, int levels);
 // level 0 from a row-major image, then the box-filtered levels; chain is in the blocked layout of DevTex8
-void launch_build_mips_rgba8(hipStream_t s, const uint32_t* linear_level0, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb);
+// srgb_tables: 256 decoded values, then the 257 store thresholds of the 8-bit sRGB codes
+void launch_build_mips_rgba8(hipStream_t s, const uint32_t* linear_level0, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb,
+                             const float* srgb_tables);
 void launch_equirect_to_cube(hipStream_t s, DevEquirect hdr, float4* out, int size);
 void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int n_phi, int n_theta, float4* out, int size);
 void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, float inv_weight,
