@@ -169,7 +169,11 @@ int pbr_ibl_prefilter_kept_samples(int32_t mips, int32_t level, int32_t* kept);
 int pbr_draw_frame(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1,
                    uint8_t* rgba8_out, uint32_t* vis_out, PbrFrameStats* stats);
 /* Same pass with outputs left in device memory (d_vis may be NULL); returns without synchronising
- * unless stats is given. */
+ * unless stats is given.  The working buffers for clipped and binned triangles are sized for views from outside
+ * the scene; a frame that overflows one (a camera inside a dense instanced scene can) is incomplete.  pbr_draw_frame,
+ * and this call with stats, notice, enlarge the buffer to its worst case and draw the frame again; this call without
+ * stats only queues the frame, and the overflow is reported, and the buffer enlarged for the following frames, by the
+ * next pbr_synchronize (PBR_E_STATE, "draw it again"). */
 int pbr_draw_frame_device(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1,
                           void* d_rgba8, void* d_vis, PbrFrameStats* stats);
 /* pbr_draw_frame_device for callers that cannot allocate device memory: code under HIP graph capture, serving
@@ -191,6 +195,9 @@ int pbr_debug_vertex_stage(PbrContext* ctx, const PbrFrameUniforms* u, float* cl
  * w x h rgba8, top row first; rgba8_out == NULL only reports the level's size.  For verification of the mip chain
  * (the per-level 8-bit rounding and, for the sRGB formats, the decode - average - encode of every level). */
 int pbr_debug_texture_level(PbrContext* ctx, int slot, int32_t level, uint8_t* rgba8_out, size_t out_bytes, int32_t* w, int32_t* h);
+/* Test hook: exact capacities of the set-up triangle buffer and of the tile-reference overflow list (0 = the
+ * library's own sizing) until an overflow enlarges them, so that the overflow handling can be exercised. */
+int pbr_debug_set_capacity(PbrContext* ctx, size_t setup_triangles, size_t overflow_refs);
 /* The depth buffer normally lives only in on-chip memory during rasterisation; enable capture to
  * have the following frames also write it to device memory so pbr_debug_depth can return it. */
 int pbr_debug_capture_depth(PbrContext* ctx, int32_t enable);

@@ -511,6 +511,49 @@ def test_instanced_grid_matches_oracle():
         s.renderer.close()
 
 
+def test_working_buffer_overflow_is_noticed_and_repaired():
+    """A camera inside a 3 x 3 grid of helmets (triangles cut by the near plane leave several pieces each), with the
+    set-up buffer and the tile-reference list forced far too small: the synchronous entry point enlarges them and
+    returns the oracle's frame; the queued one reports the incomplete frame at the next synchronize and draws the
+    following frame correctly.  Then the same view with the library's own sizing."""
+    pkg = pu._pkg()
+    lib = pkg._lib
+    g = pkg.glTFLoader(); g.load(pkg.renderer.DEFAULT_MODEL)
+    base = g.get_geometries()[0].model
+    models = np.stack([pkg.mathx.mul(pkg.mathx.translate(pkg.mathx.identity(), [(i - 1) * 2.5, (j - 1) * 2.5, 0.0]), base) for j in range(3) for i in range(3)])
+    s = pu.SmallScene.build(width=480, height=270, instance_models=models)
+    r = s.renderer
+    try:
+        import torch
+        r.camera.update_camera_distance(430.0, 0.0)          # 0.7 units from the centre helmet's origin: inside it
+        r.camera.update_camera_rotation(-300.0, 150.0)
+        orgba, ovis = s.render_oracle()
+        assert 0.1 < (ovis > 0).mean()                      # seen from inside, most of what faces the camera is culled back faces
+        lib.check(r._ctx, r._lib.pbr_debug_set_capacity(r._ctx, 1500, 64))
+        rgba, vis, st = r.draw_frame(want_vis=True, want_stats=True)          # notices, enlarges, draws again
+        assert (vis == ovis).all() and st.setup_triangles > 1500
+        assert_frame_close(rgba, orgba, vis, ovis, "inside the grid, after the repair")
+        # the queued path: the incomplete frame is reported by the next synchronize, the one after it is whole
+        lib.check(r._ctx, r._lib.pbr_debug_set_capacity(r._ctx, 1500, 64))
+        out = torch.zeros((270, 480, 4), dtype=torch.uint8, device="cuda:0")
+        r.draw_frame_device(out.data_ptr())
+        with pytest.raises(lib.PbrError, match="draw it again"):
+            r.synchronize()
+        r.draw_frame_device(out.data_ptr())
+        r.synchronize()
+        assert (out.cpu().numpy() == rgba).all()
+        # tile-reference list alone too small
+        lib.check(r._ctx, r._lib.pbr_debug_set_capacity(r._ctx, 0, 16))
+        rgba2, vis2 = s.render_gpu()
+        assert (vis2 == ovis).all() and (rgba2 == rgba).all()
+        # the library's own sizing, from scratch
+        lib.check(r._ctx, r._lib.pbr_debug_set_capacity(r._ctx, 0, 0))
+        rgba3, vis3 = s.render_gpu()
+        assert (vis3 == ovis).all() and (rgba3 == rgba).all()
+    finally:
+        r.close()
+
+
 def test_stress_scene_strips_at_full_size():
     """The synthetic stress scene at full size: 10 x 10 instanced helmets (1.5 M triangles), 7680 x 4320, eight 540-row strips
     (the screen-strip split over eight GPUs, here one after the other on one): the strips put together are the

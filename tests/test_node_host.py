@@ -135,6 +135,32 @@ def test_hdr_older_encodings_python(older_hdrs, pkg):
             pkg.HDRLoader().load(path)
 
 
+ZERO_EXPONENT_HDR = (b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 8\n" +
+                     bytes([2, 2, 0, 8, 0x88, 200, 0x88, 100, 0x88, 50, 0x84, 0, 0x84, 129]))   # 4 pixels (200,100,50,e=0), 4 with e=129
+
+
+def test_hdr_zero_exponent_python(pkg):
+    """hdr.ts:105-116 has no special case for an exponent byte of 0 and returns mantissa * 2^-128 / 255; the Radiance
+    format defines such a pixel as black.  The default loader keeps the reference's value, the opt-in one the format's."""
+    ref = pkg.HDRLoader(); ref.load_bytes(ZERO_EXPONENT_HDR)
+    fmt = pkg.HDRLoader(reference_limits=False); fmt.load_bytes(ZERO_EXPONENT_HDR)
+    a, b = ref.hdr.data.reshape(8, 4), fmt.hdr.data.reshape(8, 4)
+    tiny = np.float32(2.0 ** -128 / 255.0)
+    want = (np.array([200, 100, 50, 0], np.float64) * 2.0 ** -128 / 255.0 + np.array([0, 0, 0, 1])).astype(np.float32)
+    assert np.array_equal(a[0], want) and 0 < a[0, 2] < 1e-36 and tiny > 0
+    assert np.array_equal(b[0], [0.0, 0.0, 0.0, 1.0]) and np.array_equal(b[:4], np.tile(b[0], (4, 1)))
+    assert np.array_equal(a[4:], b[4:]) and np.allclose(a[4], [200 * 2 / 255, 100 * 2 / 255, 50 * 2 / 255, 1.0])
+
+
+@needs_node
+def test_hdr_zero_exponent_js(js_dump, pkg):
+    ref = pkg.HDRLoader(); ref.load_bytes(ZERO_EXPONENT_HDR)
+    fmt = pkg.HDRLoader(reference_limits=False); fmt.load_bytes(ZERO_EXPONENT_HDR)
+    for got, want in zip(js_dump["hdrZero"], (ref, fmt)):
+        w = want.hdr.data.reshape(8, 4)
+        assert np.array_equal(np.array(got, np.float32), np.concatenate([w[0], w[4]]).astype(np.float32))
+
+
 @needs_node
 def test_hdr_older_encodings_js(js_dump, older_hdrs, pkg):
     ref = pkg.HDRLoader()

@@ -60,6 +60,7 @@ EXPORTS = {
     "pbr_draw_frame_static": (C.c_int, [C.c_void_p, C.POINTER(FrameUniforms), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pbr_debug_vertex_stage": (C.c_int, [C.c_void_p, C.POINTER(FrameUniforms), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pbr_debug_texture_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "pbr_debug_set_capacity": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t]),
     "pbr_debug_capture_depth": (C.c_int, [C.c_void_p, C.c_int32]),
     "pbr_debug_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "pbr_profile_begin": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -249,14 +249,24 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int sample
     HIP_TRY(c, hipMalloc(&c->d_records, ntri * sizeof(TriRecord)));
     c->record_cap = ntri; grew = true;
   }
-  const size_t want_setup = ntri + ntri / 4 + 4096;
-  if (want_setup > c->setup_cap) {
+  // Set-up triangles: every triangle that survives culling, plus the pieces of clipped ones.  A quarter more than the
+  // mesh is ample for views from outside; a triangle cut by several planes leaves up to seven pieces, so a view from
+  // inside a dense scene can exceed it.  The kernels then drop what does not fit and raise a flag; the library, when it
+  // sees the flag, enlarges the buffer to that worst case (want_capacity) and the frame is drawn again.
+  const size_t want_setup = c->forced_setup_cap ? c->forced_setup_cap : std::max(ntri + ntri / 4 + 4096, c->min_setup_cap);
+  if (want_setup > c->setup_cap || (c->forced_setup_cap && want_setup != c->setup_cap)) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    free_dev(c->d_setup); free_dev(c->d_overflow);
+    free_dev(c->d_setup);
     HIP_TRY(c, hipMalloc(&c->d_setup, want_setup * sizeof(SetupTri)));
     c->setup_cap = want_setup;
-    c->overflow_cap = want_setup * 2 + (1u << 16);
-    HIP_TRY(c, hipMalloc(&c->d_overflow, c->overflow_cap * sizeof(uint2)));
+    grew = true;
+  }
+  const size_t want_overflow = c->forced_overflow_cap ? c->forced_overflow_cap : std::max(want_setup * 2 + (1u << 16), c->min_overflow_cap);
+  if (want_overflow > c->overflow_cap || (c->forced_overflow_cap && want_overflow != c->overflow_cap)) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    free_dev(c->d_overflow);
+    HIP_TRY(c, hipMalloc(&c->d_overflow, want_overflow * sizeof(uint2)));
+    c->overflow_cap = want_overflow;
     grew = true;
   }
   if ((size_t)n_tiles > c->tile_cap) {
@@ -323,7 +333,13 @@ static int check_sticky(PbrContext* c) {
       const uint32_t code = c->h_counters[8 * set + 2];
       c->h_counters[8 * set + 2] = 0;
       (void)hipMemset(&c->d_counters[8 * set + 2], 0, sizeof(uint32_t));
-      return fail(c, PBR_E_STATE, code == 1 ? "triangle setup buffer overflow" : "tile bin overflow list full");
+      // enlarge for the frames to come: the worst case for the set-up buffer, four times the list for the tile references
+      const size_t ntri = (size_t)(assets_of(c)->n_indices / 3) * assets_of(c)->n_instances;
+      if (code == 1) { c->min_setup_cap = 7 * ntri + 4096; c->forced_setup_cap = 0; }
+      else { c->min_overflow_cap = std::max(c->overflow_cap, (size_t)1 << 16) * 4; c->forced_overflow_cap = 0; }
+      c->enlarged_after_overflow = true;
+      return fail(c, PBR_E_STATE, code == 1 ? "triangle setup buffer overflow: a frame is incomplete; the buffer has been enlarged, draw it again"
+                                            : "tile bin overflow list full: a frame is incomplete; the list has been enlarged, draw it again");
     }
   }
   return PBR_OK;
@@ -1017,7 +1033,15 @@ int pbr_draw_frame_device(PbrContext* c, const PbrFrameUniforms* u, int32_t w, i
                           PbrFrameStats* stats) {
   if (!c) return PBR_E_ARG;
   if (!d_rgba8) return fail(c, PBR_E_ARG, "colour output pointer is null");
-  return draw_common(c, u, w, h, y0, y1, d_rgba8, d_vis, false, stats);
+  // with statistics the call synchronises and sees a capacity overflow itself: the buffers have then been enlarged and
+  // the frame is drawn again; without, the frame is only queued and an overflow is reported by pbr_synchronize
+  int rc = PBR_OK;
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    c->enlarged_after_overflow = false;
+    rc = draw_common(c, u, w, h, y0, y1, d_rgba8, d_vis, false, stats);
+    if (!(rc == PBR_E_STATE && c->enlarged_after_overflow)) break;
+  }
+  return rc;
 }
 
 int pbr_draw_frame_static(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1, void* d_rgba8) {
@@ -1035,16 +1059,31 @@ int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t 
   // make sure the internal colour / visibility buffers exist at this size before drawing into them
   const int rows = y1 - y0;
   const int samples = (u && (u->sampler_index & 16u)) ? 4 : 1;
-  int rc = ensure_frame_buffers(c, w, rows, ((w + PBR_TILE - 1) / PBR_TILE) * ((rows + PBR_TILE - 1) / PBR_TILE), samples);
-  if (rc) return rc;
-  rc = draw_common(c, u, w, h, y0, y1, c->d_color, nullptr, vis_out != nullptr, stats);
-  if (rc) return rc;
   const size_t npix = (size_t)w * rows;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  int rc = PBR_OK;
+  for (int attempt = 0; attempt < 4; ++attempt) {   // a frame that overflowed a working buffer is drawn again into the enlarged one
+    c->enlarged_after_overflow = false;
+    rc = ensure_frame_buffers(c, w, rows, ((w + PBR_TILE - 1) / PBR_TILE) * ((rows + PBR_TILE - 1) / PBR_TILE), samples);
+    if (rc) return rc;
+    rc = draw_common(c, u, w, h, y0, y1, c->d_color, nullptr, vis_out != nullptr, stats);
+    if (rc == PBR_OK) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      rc = check_sticky(c);
+    }
+    if (!(rc == PBR_E_STATE && c->enlarged_after_overflow)) break;
+  }
+  if (rc) return rc;
   HIP_TRY(c, hipMemcpy(rgba8_out, c->d_color, npix * 4, hipMemcpyDeviceToHost));
   if (vis_out) HIP_TRY(c, hipMemcpy(vis_out, c->d_vis, npix * samples * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  return check_sticky(c);
+  return PBR_OK;
+}
+
+int pbr_debug_set_capacity(PbrContext* c, size_t setup_triangles, size_t overflow_refs) {
+  if (!c) return PBR_E_ARG;
+  c->forced_setup_cap = setup_triangles; c->forced_overflow_cap = overflow_refs;
+  c->min_setup_cap = 0; c->min_overflow_cap = 0;
+  return PBR_OK;
 }
 
 int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip, float* world, float* normal) {

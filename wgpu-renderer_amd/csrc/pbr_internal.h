@@ -149,6 +149,9 @@ struct PbrContext {
   uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0; uint32_t* d_tile_live = nullptr;   // [tiles], [tiles][PBR_BIN_CAP]
   QuadLists quad_lists = {nullptr, nullptr, nullptr};                                  // work lists of the resolve, each [tiles * 256]
   uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
+  size_t min_setup_cap = 0, min_overflow_cap = 0;         // raised when a frame overflowed one of the two
+  size_t forced_setup_cap = 0, forced_overflow_cap = 0;   // pbr_debug_set_capacity: exact capacities, until an overflow enlarges them
+  bool enlarged_after_overflow = false;
   uint32_t* d_counters = nullptr; // two sets of 8, used by alternate frames: [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6], [7] uniform and mixed quads
   bool capture_depth = false;
   uint32_t* h_counters = nullptr; // pinned mirror

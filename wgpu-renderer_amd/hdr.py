@@ -19,7 +19,9 @@ class HDRLoader:
     """`reference_limits=True` (default) keeps the reference's parser exactly, errors included: only
     new-style RLE scanlines.  With False the loader also reads the two older scanline encodings of
     the Radiance format (flat RGBE pixels, and runs marked by a (1,1,1,n) pixel), which the
-    reference rejects with "Only support RLE format."."""
+    reference rejects with "Only support RLE format.", and gives a pixel whose exponent byte is 0
+    the value the format defines for it, black, where the reference (hdr.ts:105-116 has no special
+    case) returns mantissa * 2^-128 / 255."""
 
     def __init__(self, reference_limits=True):
         self.reference_limits = reference_limits
@@ -100,6 +102,8 @@ class HDRLoader:
         # hdr.ts:105-116: rgb = mantissa * 2^(e-128) / 255, no e == 0 special case
         e = scan[..., 3].astype(np.float64)
         scale = np.exp2(e - 128.0) / 255.0
+        if not self.reference_limits:
+            scale[scan[..., 3] == 0] = 0.0      # exponent byte 0: the format's encoding of black
         out = np.empty((h, w, 4), dtype=np.float32)
         out[..., :3] = (scan[..., :3].astype(np.float64) * scale[..., None]).astype(np.float32)
         out[..., 3] = 1.0

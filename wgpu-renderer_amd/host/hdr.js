@@ -3,7 +3,9 @@
 // `await load(url)`, `.hdr` = { width, height, data: Float32Array rgba }.  `url` is a filesystem
 // path.  By default the limits are the reference's: new-style RLE scanlines only, no special case
 // for e == 0.  `new HDRLoader({ referenceLimits: false })` also reads the two older scanline encodings
-// of the format (flat RGBE pixels, and runs marked by a (1,1,1,n) pixel), which the reference rejects.
+// of the format (flat RGBE pixels, and runs marked by a (1,1,1,n) pixel), which the reference rejects, and
+// decodes a pixel whose exponent byte is 0 to black, as the format defines it (the reference returns
+// mantissa * 2^-128 / 255 for it, hdr.ts:105-116).
 const fs = require('fs');
 
 class HDRLoader {
@@ -81,7 +83,8 @@ class HDRLoader {
     // hdr.ts:105-116: rgb = mantissa * 2^(e - 128) / 255, alpha 1
     const data = new Float32Array(w * h * 4);
     for (let i = 0; i < w * h; ++i) {
-      const scale = Math.pow(2, scan[4 * i + 3] - 128) / 255;
+      const e = scan[4 * i + 3];
+      const scale = (e === 0 && !this.referenceLimits) ? 0 : Math.pow(2, e - 128) / 255;
       data[4 * i] = scan[4 * i] * scale;
       data[4 * i + 1] = scan[4 * i + 1] * scale;
       data[4 * i + 2] = scan[4 * i + 2] * scale;

@@ -33,6 +33,14 @@ const hex = (typed) => Buffer.from(typed.buffer, typed.byteOffset, typed.byteLen
     await l.load(older);
     out.hdrOlder.push({ width: l.hdr.width, height: l.hdr.height, data: sha(l.hdr.data) });
   }
+  // a pixel with exponent byte 0, through the reference-faithful and the format-faithful loader
+  out.hdrZero = [];
+  for (const referenceLimits of [true, false]) {
+    const l = new host.HDRLoader({ referenceLimits });
+    l.buffer = Buffer.concat([Buffer.from('#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 8\n'), Buffer.from([2, 2, 0, 8, 0x88, 200, 0x88, 100, 0x88, 50, 0x84, 0, 0x84, 129])]);
+    l.parseHDR();
+    out.hdrZero.push(Array.from(l.hdr.data.slice(0, 4)).concat(Array.from(l.hdr.data.slice(16, 20))));
+  }
   const image = await host.utils.loadImageBitmap(jpegPath);
   out.image = { width: image.width, height: image.height, data: sha(image.data) };
   const r = new host.Renderer({ width: 1280, height: 720, hdr: hdrLoader.hdr });
