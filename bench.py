@@ -5,7 +5,7 @@ Default mode (`--mode orbit`): a step is one 3840x2160 DamagedHelmet PBR+IBL fra
 raster + skybox, surface shading) rendered into device memory with every input already resident in HBM.  With
 --gpus N > 1 the frames of a camera orbit (one `updateCameraRotation(-10, 0)` step per frame) are dealt round-robin
 to the ranks, one process per GPU, no data-path collective: weak scaling.  Each rank keeps --in-flight frames in
-flight (default 3): one renderer context plus forks of it, which share ONE copy of the scene on the device and each
+flight (default 4): one renderer context plus forks of it, which share ONE copy of the scene on the device and each
 own a stream and a colour target, take the rank's frames in turn, so the short latency-bound geometry kernels of
 one frame overlap the shading of the previous one.  `config.single_frame_ms` is the same frame with nothing else in
 flight.
@@ -88,7 +88,7 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--skybox-size", type=int, default=1024)
-    ap.add_argument("--in-flight", type=int, default=3,
+    ap.add_argument("--in-flight", type=int, default=4,
                     help="frames in flight per GPU: one renderer context plus forks of it, each on its own stream, take the rank's frames in turn")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the IBL prefilter timing (2048^2, 10 mips)")

@@ -64,7 +64,7 @@ def test_gpus_flag_without_a_launcher_does_not_report_one_gpu(tmp_path):
 def test_modes_and_their_defaults():
     b = _bench()
     a = b.parse_args([])
-    assert (a.mode, a.width, a.height, a.steps, a.warmup, a.in_flight) == ("orbit", 3840, 2160, 360, 20, 3)
+    assert (a.mode, a.width, a.height, a.steps, a.warmup, a.in_flight) == ("orbit", 3840, 2160, 360, 20, 4)
     s = b.parse_args(["--mode", "strips"])
     assert (s.width, s.height, s.steps) == (7680, 4320, 20)
 
