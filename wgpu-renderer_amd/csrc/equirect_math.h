@@ -9,9 +9,9 @@
 
 // Largest distance, in radians, seen between these functions and the device library's over 2^33 directions (a
 // quarter of them hugging the poles, the seam and the axes; scripts/equirect_approx_check.hip) is 2.4e-7 for atan2
-// and 1.2e-7 for asin; the guards are four and five times that.
-#define EQUIRECT_ATAN2_GUARD 1.0e-6f
-#define EQUIRECT_ASIN_GUARD 6.0e-7f
+// and 1.2e-7 for asin (one unit in the last place of the largest results, in both cases); the guards are twice that.
+#define EQUIRECT_ATAN2_GUARD 5.0e-7f
+#define EQUIRECT_ASIN_GUARD 2.5e-7f
 
 // atan2(y, x): octant reduction to a = min / max in [0, 1], odd minimax polynomial of degree 15 (1.4e-7 in f32).
 PBR_DEV float atan2_fast(float y, float x) {

@@ -116,6 +116,11 @@ __global__ void __launch_bounds__(256) block_rgba8_kernel(const uint32_t* __rest
   dst[tex8_block_offset(x, y, w)] = src[(size_t)y * w + x];
 }
 
+__global__ void __launch_bounds__(256) drop_alpha_kernel(const float4* __restrict__ rgba, float* __restrict__ rgb, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { const float4 t = rgba[i]; rgb[3 * i] = t.x; rgb[3 * i + 1] = t.y; rgb[3 * i + 2] = t.z; }
+}
+
 __global__ void __launch_bounds__(256) equirect_to_cube_kernel(DevEquirect hdr, float4* __restrict__ out, int size) {
   int gx = blockIdx.x * 64 + (threadIdx.x & 63), gy = blockIdx.y * 4 + (threadIdx.x >> 6), gz = blockIdx.z;
   if (gx >= size || gy >= size) return;
@@ -237,8 +242,9 @@ __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const P
       x1 = max(min((int)(u * (float)w1), w1 - 1), 0); y1 = max(min((int)(v * (float)h1), h1 - 1), 0);   // not POW2: always the library path
       row0 = (uint32_t)y0 * (uint32_t)w0; row1 = (uint32_t)y1 * (uint32_t)w1;
     }
-    const float4 a = hdr.base[hdr.off[s.l0] + row0 + (uint32_t)x0];
-    const float4 c = hdr.base[hdr.off[s.l1] + row1 + (uint32_t)x1];
+    const float* qa = hdr.rgb + 3 * (size_t)(hdr.off[s.l0] + row0 + (uint32_t)x0);
+    const float* qc = hdr.rgb + 3 * (size_t)(hdr.off[s.l1] + row1 + (uint32_t)x1);
+    const V3 a = v3(qa[0], qa[1], qa[2]), c = v3(qc[0], qc[1], qc[2]);   // one 12-byte load each
     const float wa = s.wa, wc = s.wc;
     r += a.x * wa + c.x * wc; g += a.y * wa + c.y * wc; b += a.z * wa + c.z * wc;
   }
@@ -313,6 +319,10 @@ void launch_build_mips_rgba8(hipStream_t s, const uint32_t* linear_level0, uint3
     dim3 grid((dw + 63) / 64, (dh + 3) / 4);
     hipLaunchKernelGGL(mip_rgba8_kernel, grid, dim3(256), 0, s, chain + off[l - 1], chain + off[l], sw, sh, dw, dh, srgb, srgb_tables);
   }
+}
+
+void launch_drop_alpha(hipStream_t s, const float4* rgba, float* rgb, size_t texels) {
+  hipLaunchKernelGGL(drop_alpha_kernel, dim3((unsigned)((texels + 255) / 256)), dim3(256), 0, s, rgba, rgb, texels);
 }
 
 void launch_equirect_to_cube(hipStream_t s, DevEquirect hdr, float4* out, int size) {

@@ -649,7 +649,7 @@ int pbr_destroy(PbrContext* c) {
   PbrContextPrivate* pr = priv_of(c);
   free_dev(c->d_vsoa); free_dev(c->d_indices); free_dev(c->d_inst_model); free_dev(c->d_inst_normal);
   for (auto& t : c->d_tex) free_dev(t);
-  free_dev(c->d_hdr); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
+  free_dev(c->d_hdr); free_dev(c->d_hdr_rgb); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
   { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); free_dev(pr->d_lut_pair); }
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
   free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
@@ -784,6 +784,11 @@ int pbr_upload_hdr(PbrContext* c, const float* rgba32f, int32_t w, int32_t h) {
   e.base = c->d_hdr;
   HIP_TRY(c, hipMemcpyAsync(c->d_hdr, rgba32f, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   launch_build_mips_rgba32f(c->stream, c->d_hdr, e.off, w, h, e.levels);
+  // the prefilter's gathers fetch three floats per source pixel instead of four from this copy
+  free_dev(c->d_hdr_rgb);
+  HIP_TRY(c, hipMalloc(&c->d_hdr_rgb, total * 3 * sizeof(float)));
+  e.rgb = c->d_hdr_rgb;
+  launch_drop_alpha(c->stream, c->d_hdr, c->d_hdr_rgb, total);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   priv_of(c)->prefilter_tables_for = -1;

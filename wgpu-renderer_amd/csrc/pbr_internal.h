@@ -50,6 +50,7 @@ struct DevCubeRgb {
 // An equirectangular rgba32f image with its mip chain.
 struct DevEquirect {
   const float4* base;
+  const float* rgb;               // the same chain without its alpha (always 1), three floats per texel: what the prefilter gathers from
   uint32_t off[PBR_MAX_LEVELS];
   int32_t w, h, levels;
 };
@@ -133,6 +134,7 @@ struct PbrContext {
 
   // HDR + IBL
   float4* d_hdr = nullptr;
+  float* d_hdr_rgb = nullptr;
   DevEquirect hdr = {};
   float4* d_sky = nullptr;   DevCube sky = {};
   float4* d_irr = nullptr;   DevCube irr = {};
@@ -171,6 +173,7 @@ void launch_build_mips_rgba32f(hipStream_t s, float4* chain, const uint32_t* off
 // srgb_tables: 256 decoded values, then the 257 store thresholds of the 8-bit sRGB codes
 void launch_build_mips_rgba8(hipStream_t s, const uint32_t* linear_level0, uint32_t* chain, const uint32_t* off, int w, int h, int levels, int srgb,
                              const float* srgb_tables);
+void launch_drop_alpha(hipStream_t s, const float4* rgba, float* rgb, size_t texels);
 void launch_equirect_to_cube(hipStream_t s, DevEquirect hdr, float4* out, int size);
 void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int n_phi, int n_theta, float4* out, int size);
 void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, float inv_weight,
