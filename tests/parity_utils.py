@@ -1,5 +1,6 @@
 """Shared scaffolding for the parity tests: builds one scene twice — through the product's
 C ABI (GPU) and through the CPU oracle — from the same inputs."""
+import contextlib
 import ctypes as C
 import os
 
@@ -64,6 +65,20 @@ class OracleScene:
             _, lut16 = ob.brdf_lut(self.lut_size)
             self._maps = {"sky": sky, "irr": irr, "pre": pre_levels, "lut": lut16}
         return self._maps
+
+    @contextlib.contextmanager
+    def with_maps(self, maps):
+        """Shade from the given IBL maps (same keys and shapes as maps()) instead of the oracle's own: with the maps
+        another implementation generated, the frames differ only by what the frame path itself does differently."""
+        own = self.maps()
+        for k in ("sky", "irr", "lut"):
+            assert maps[k].shape == own[k].shape and maps[k].dtype == own[k].dtype, k
+        assert [p.shape for p in maps["pre"]] == [p.shape for p in own["pre"]]
+        self._maps = maps
+        try:
+            yield self
+        finally:
+            self._maps = own
 
     def c_scene(self):
         m = self.maps()
@@ -177,6 +192,13 @@ class SmallScene:
 
     def render_oracle_with_margins(self, y0=0, y1=None):
         return self.oracle.draw_with_margins(self.uniforms(), self.width, self.height, y0, y1)
+
+    def gpu_maps(self):
+        """The IBL maps as the device holds them, in the layout of OracleScene.maps()."""
+        lib, r = self.pkg._lib, self.renderer
+        return {"sky": r.download_map(lib.MAP_SKYBOX), "irr": r.download_map(lib.MAP_IRRADIANCE),
+                "pre": [r.download_map(lib.MAP_PREFILTER, lvl) for lvl in range(self.oracle.pre_mips)],
+                "lut": r.download_map(lib.MAP_BRDF_LUT)}
 
 
 def psnr(a, b):

@@ -81,7 +81,10 @@ def assert_only_fragile_pixels_differ(rgba, ref_rgba, margin, name, share=0.005)
     assert n_off <= share * d.size + 1, f"{name}: {n_off} pixels beyond 2/255"
 
 
-def assert_frame_close(rgba, ref_rgba, vis, ref_vis, name=""):
+def assert_frame_close(rgba, ref_rgba, vis, ref_vis, name="", margin=None, slack=LOD_SLACK):
+    if margin is not None:      # every pixel beyond 2/255 must be one whose sampling decisions sat on a switching point
+        far = np.abs(rgba.astype(np.int32) - ref_rgba.astype(np.int32)).max(-1) > 2
+        assert (margin[far] < slack).all(), f"{name}: {int((far & (margin >= slack)).sum())} pixels beyond 2/255 without a sampling decision near its switching point"
     assert vis.shape == ref_vis.shape
     match = (vis == ref_vis).mean()
     assert match >= 0.999, f"{name}: visibility match {match:.6f}"
@@ -265,30 +268,32 @@ def test_camera_views_match_oracle(small, moves):
         {"rotate": cam.update_camera_rotation, "dolly": cam.update_camera_distance, "track": cam.update_camera_target}[kind](dx, dy)
     small.renderer.camera = cam
     rgba, vis = small.render_gpu()
-    orgba, ovis = small.render_oracle()
+    orgba, ovis, margin = small.render_oracle_with_margins()
     assert (vis == ovis).all()
-    assert_frame_close(rgba, orgba, vis, ovis, str(moves))
+    assert_frame_close(rgba, orgba, vis, ovis, str(moves), margin)
     small.renderer.camera = small.pkg.Camera()
 
 
 def test_orbit_sweep_matches_oracle(small):
     """Every tenth frame of the 360-frame orbit of the benchmark (updateCameraRotation(-10, 0) per frame, camera.ts:163-183):
     the visibility buffer is the oracle's on every frame, the colours stay within the frame tolerance.  A few
-    pixels per million differ by more: all the pixels of one triangle in a quad it shares with others, as when
-    derivatives that differ in the last bits (reciprocal approximations, FMA contraction) put the mip level on
-    the other side of a rounding boundary."""
+    pixels per million differ by more, and every one of them is a pixel where the oracle's own mip-level decision sat
+    within LOD_SLACK of its switching point (derivatives that differ in the last bits - reciprocal approximations,
+    FMA contraction - put the level on the other side)."""
     cam = small.pkg.Camera()
     small.renderer.camera = cam
     beyond, mismatched = 0, 0
     for frame in range(0, 360, 10):
         rgba, vis = small.render_gpu()
-        orgba, ovis = small.render_oracle()
+        orgba, ovis, margin = small.render_oracle_with_margins()
         assert (vis == ovis).all(), frame
         _, d = assert_frame_close(rgba, orgba, vis, ovis, f"orbit frame {frame}")
+        assert (margin[d > 2] < LOD_SLACK).all(), (frame, int((d > 2).sum()))
         beyond += int((d > 2).sum()); mismatched += int((d > 0).sum())
         for _ in range(10):
             cam.update_camera_rotation(-10.0, 0.0)
     pixels = 36 * small.width * small.height
+    print(f"orbit sweep: {beyond} of {pixels} pixels beyond 2/255, every one with a decision margin below {LOD_SLACK:g}; {mismatched} differ at all")
     assert beyond / pixels <= 5e-6 and mismatched / pixels < 0.02, (beyond, mismatched)
     small.renderer.camera = small.pkg.Camera()
 
@@ -301,7 +306,7 @@ def test_near_plane_clipping_matches_oracle(small):
     assert abs(float(np.linalg.norm(cam.eye)) - 1.25) < 1e-3
     small.renderer.camera = cam
     rgba, vis = small.render_gpu()
-    orgba, ovis = small.render_oracle()
+    orgba, ovis, margin = small.render_oracle_with_margins()
     assert (vis > 0).mean() > 0.1
     # the view really exercises the clipper: many triangles straddle the plane z_clip = 0
     o = small.oracle
@@ -312,7 +317,7 @@ def test_near_plane_clipping_matches_oracle(small):
     behind = (clip[:, 2] < 0)[o.indices.reshape(-1, 3)].sum(1)
     assert ((behind > 0) & (behind < 3)).sum() > 100
     assert (vis == ovis).mean() >= 0.9999
-    assert_frame_close(rgba, orgba, vis, ovis, "near clip")
+    assert_frame_close(rgba, orgba, vis, ovis, "near clip", margin)
     small.renderer.camera = small.pkg.Camera()
 
 
@@ -356,9 +361,12 @@ def test_multisampled_pipeline_matches_oracle(small, sampler_index, moves):
         assert r.frame_uniforms().sampler_index == sampler_index + 16
         lib.check(r._ctx, r._lib.pbr_debug_capture_depth(r._ctx, 1))
         rgba, vis, stats = r.draw_frame(want_vis=True, want_stats=True)
-        orgba, ovis = small.render_oracle()
+        orgba, ovis, margin = small.render_oracle_with_margins()
         assert vis.shape == (small.height, small.width, 4) and (vis == ovis).all()
-        assert_frame_close(rgba, orgba, vis, ovis, f"msaa sampler {sampler_index} {moves}")
+        # A multisampled pixel whose centre lies outside the triangle is shaded from EXTRAPOLATED attributes
+        # (shader.wgsl's inputs carry no centroid qualifier), and on a sliver the extrapolation multiplies the rounding
+        # differences of the two interpolations: texel coordinates were seen 0.003 apart, so the switching band is wider.
+        assert_frame_close(rgba, orgba, vis, ovis, f"msaa sampler {sampler_index} {moves}", margin, slack=4 * LOD_SLACK)
         depth = np.zeros(vis.shape, np.float32)
         lib.check(r._ctx, r._lib.pbr_debug_depth(r._ctx, ob.ptr(depth), depth.size))
         _, odepth = small.oracle.raster(small.uniforms(), small.width, small.height)
@@ -457,6 +465,12 @@ def test_reference_sizes_720p(refsize):
     orgba, ovis = refsize.render_oracle()
     assert (vis == ovis).all()
     assert_frame_close(rgba, orgba, vis, ovis, "720p")
+    # The maps above agree up to source pixels that may fall either way (their reachable intervals were just checked);
+    # a frame shaded from them inherits those texels.  Shaded from the SAME maps, every pixel beyond 2/255 must be
+    # one whose own sampling decisions sat on a switching point.
+    with refsize.oracle.with_maps(refsize.gpu_maps()):
+        orgba, ovis, margin = refsize.render_oracle_with_margins()
+    assert_frame_close(rgba, orgba, vis, ovis, "720p from the device's maps", margin)
 
 
 def test_4k_frame_properties(refsize):
@@ -474,9 +488,10 @@ def test_4k_frame_properties(refsize):
         ids = np.unique(vis[vis > 0]) - 1
         assert ids.max() < 15452 and len(ids) > 3000
         y0, y1 = 1040, 1120
-        orgba, ovis = refsize.render_oracle(y0, y1)
+        with refsize.oracle.with_maps(refsize.gpu_maps()):
+            orgba, ovis, margin = refsize.render_oracle_with_margins(y0, y1)
         assert (vis[y0:y1] == ovis).all()
-        assert_frame_close(rgba[y0:y1], orgba, vis[y0:y1], ovis, "4K band")
+        assert_frame_close(rgba[y0:y1], orgba, vis[y0:y1], ovis, "4K band", margin)
         srgba, svis = refsize.render_gpu(y0, y1)
         assert (srgba == rgba[y0:y1]).all() and (svis == vis[y0:y1]).all()
         # sky rows: top band against the oracle
@@ -503,10 +518,10 @@ def test_instanced_grid_matches_oracle():
         s.renderer.camera.update_camera_distance(-700.0, 0.0)      # dolly out to 12 units
         s.renderer.camera.update_camera_rotation(-200.0, 100.0)
         rgba, vis = s.render_gpu()
-        orgba, ovis = s.render_oracle()
+        orgba, ovis, margin = s.render_oracle_with_margins()
         assert (vis == ovis).all()
         assert len(np.unique((vis[vis > 0] - 1) // 15452)) == 9       # all nine instances visible
-        assert_frame_close(rgba, orgba, vis, ovis, "instanced")
+        assert_frame_close(rgba, orgba, vis, ovis, "instanced", margin)
     finally:
         s.renderer.close()
 
@@ -575,9 +590,9 @@ def test_stress_scene_strips_at_full_size():
             srgba, svis = s.render_gpu(y0, y1)
             assert (srgba == rgba[y0:y1]).all() and (svis == vis[y0:y1]).all(), k
         y0, y1 = 2360, 2392                                                           # through the helmets of the row below the centre
-        orgba, ovis = s.render_oracle(y0, y1)
+        orgba, ovis, margin = s.render_oracle_with_margins(y0, y1)
         assert (ovis > 0).mean() > 0.1 and (vis[y0:y1] == ovis).all()
-        assert_frame_close(rgba[y0:y1], orgba, vis[y0:y1], ovis, "8K band of the stress scene")
+        assert_frame_close(rgba[y0:y1], orgba, vis[y0:y1], ovis, "8K band of the stress scene", margin)
     finally:
         s.renderer.close()
 
