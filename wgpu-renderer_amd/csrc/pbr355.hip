@@ -314,7 +314,8 @@ struct PbrContextPrivate {
   // neighbours (and the three-texel mean at corners), so a bilinear lookup never leaves its face.
   struct Bordered { float* d = nullptr; DevCubeRgb cube = {}; bool dirty = true; };
   Bordered sky_b, irr_b, pre_b;
-  uint32_t* d_lut_pair = nullptr; int lut_pair_size = 0; bool lut_pair_dirty = true;   // two-channel copy of the BRDF table for the resolve
+  uint4* d_lut_quad = nullptr; int lut_quad_size = 0; bool lut_quad_dirty = true;   // footprint copy of the BRDF table for the resolve (ResolveInputs::lut_quad)
+  uint4* d_atlas = nullptr; size_t atlas_texels = 0; bool atlas_dirty = true;       // interleaved copy of five equally sized material textures (ResolveInputs::atlas)
   int surface_blocks = 0;                 // resident workgroups of the surface kernel on this device
   int counter_set = 0;                    // which of the two sets of append counters the next frame uses
   bool used_static = false;               // pbr_draw_frame_static has run: its overflow flag lives in the device's fixed array
@@ -399,6 +400,16 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // bit 16 of the sampler index selects the multisampled pipeline (renderer.ts:1927-1932, :1951-1954, :1979-1980)
   const bool msaa = (u->sampler_index & 16u) != 0u;
   const int samples = msaa ? 4 : 1;
+  // the specialised resolve covers the reference's default sampler on five power-of-two textures of one size, and reads
+  // them from one interleaved copy
+  static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
+  bool one_size = true;
+  for (int i = 0; i < 5; ++i)
+    one_size = one_size && a->tex[i].base && a->tex[i].srgb == kFormatSrgb[i] && (a->tex[i].w & (a->tex[i].w - 1)) == 0 && (a->tex[i].h & (a->tex[i].h - 1)) == 0 &&
+               a->tex[i].w == a->tex[0].w && a->tex[i].h == a->tex[0].h && a->tex[i].levels == a->tex[0].levels;
+  const bool fast = one_size && (u->sampler_index & 15u) == 15u;
+  const bool stale = apr->sky_b.dirty || !apr->sky_b.d || apr->irr_b.dirty || !apr->irr_b.d || apr->pre_b.dirty || !apr->pre_b.d || apr->lut_quad_dirty ||
+                     apr->lut_quad_size != a->lut_size || (one_size && (apr->atlas_dirty || !apr->d_atlas));
   int rc = PBR_OK;
   FrameWork fw;
   if (static_memory) {
@@ -413,8 +424,9 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     if (ntri > PBR_STATIC_MAX_TRIANGLES)
       return fail(c, PBR_E_ARG, "pbr_draw_frame_static: %zu triangles (all instances), the fixed working memory holds %d", ntri, PBR_STATIC_MAX_TRIANGLES);
     if (c->device < 0 || c->device >= kMaxDevices || !g_scratch_ptr[c->device]) return fail(c, PBR_E_STATE, "no fixed working memory on device %d", c->device);
-    if (apr->sky_b.dirty || !apr->sky_b.d || apr->irr_b.dirty || !apr->irr_b.d || apr->pre_b.dirty || !apr->pre_b.d || apr->lut_pair_dirty || apr->lut_pair_size != a->lut_size)
-      return fail(c, PBR_E_STATE, "pbr_draw_frame_static: the lookup copies of the IBL maps are not built yet; draw one frame with pbr_draw_frame_device after the last IBL call");
+    if (stale)
+      return fail(c, PBR_E_STATE, "pbr_draw_frame_static: the lookup copies of the IBL maps and material textures are not built yet; draw one frame with "
+                                  "pbr_draw_frame_device after the last IBL or texture call");
     unsigned char* base = g_scratch_ptr[c->device];
     fw.counters = reinterpret_cast<uint32_t*>(base + kCounters); fw.next_counters = fw.counters + 8;
     fw.tile_count = reinterpret_cast<uint32_t*>(base + kTileCount);
@@ -454,19 +466,32 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
 
   // The lookup copies derived from the IBL maps belong to the scene's owner and are rebuilt on its stream; a forked
   // context that finds them stale waits for that stream before its own launches read them.
-  const bool stale = apr->sky_b.dirty || !apr->sky_b.d || apr->irr_b.dirty || !apr->irr_b.d || apr->pre_b.dirty || !apr->pre_b.d || apr->lut_pair_dirty ||
-                     apr->lut_pair_size != a->lut_size;
   if (!static_memory && stale) {
     if ((rc = refresh_bordered(a, apr->sky_b, a->sky)) || (rc = refresh_bordered(a, apr->irr_b, a->irr)) || (rc = refresh_bordered(a, apr->pre_b, a->pre))) return rc;
-    if (apr->lut_pair_dirty || apr->lut_pair_size != a->lut_size) {
-      if (apr->lut_pair_size != a->lut_size) {
+    if (apr->lut_quad_dirty || apr->lut_quad_size != a->lut_size) {
+      if (apr->lut_quad_size != a->lut_size) {
         HIP_TRY(c, hipStreamSynchronize(a->stream));
-        if (apr->d_lut_pair) { (void)hipFree(apr->d_lut_pair); apr->d_lut_pair = nullptr; }
-        HIP_TRY(c, hipMalloc(&apr->d_lut_pair, (size_t)a->lut_size * a->lut_size * sizeof(uint32_t)));
-        apr->lut_pair_size = a->lut_size;
+        if (apr->d_lut_quad) { (void)hipFree(apr->d_lut_quad); apr->d_lut_quad = nullptr; }
+        HIP_TRY(c, hipMalloc(&apr->d_lut_quad, (size_t)a->lut_size * a->lut_size * sizeof(uint4)));
+        apr->lut_quad_size = a->lut_size;
       }
-      launch_lut_pair(a->stream, a->d_lut, apr->d_lut_pair, a->lut_size);
-      apr->lut_pair_dirty = false;
+      launch_lut_quad(a->stream, a->d_lut, apr->d_lut_quad, a->lut_size);
+      apr->lut_quad_dirty = false;
+    }
+    if (one_size && (apr->atlas_dirty || !apr->d_atlas)) {
+      size_t texels;
+      uint32_t off[PBR_MAX_LEVELS];
+      tex8_offsets(a->tex[0].w, a->tex[0].h, a->tex[0].levels, off, &texels);
+      if (apr->atlas_texels != texels || !apr->d_atlas) {
+        HIP_TRY(c, hipStreamSynchronize(a->stream));
+        if (apr->d_atlas) { (void)hipFree(apr->d_atlas); apr->d_atlas = nullptr; }
+        HIP_TRY(c, hipMalloc(&apr->d_atlas, texels * sizeof(uint4)));
+        apr->atlas_texels = texels;
+      }
+      const uint32_t* chains[5];
+      for (int i = 0; i < 5; ++i) chains[i] = a->tex[i].base;
+      launch_material_atlas(a->stream, chains, apr->d_atlas, texels);
+      apr->atlas_dirty = false;
     }
     if (a != c) HIP_TRY(c, hipStreamSynchronize(a->stream));
   }
@@ -476,14 +501,6 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   hipEvent_t* pe = prof ? &c->prof_events[2 * c->prof_frames] : nullptr;   // surface pass begin, end
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], s));
   uint8_t* color = static_cast<uint8_t*>(d_rgba8);
-
-  // the specialised resolve covers the reference's default sampler on power-of-two textures
-  static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
-  bool fast = (u->sampler_index & 15u) == 15u;
-  for (int i = 0; i < 5; ++i) fast = fast && a->tex[i].srgb == kFormatSrgb[i];
-  for (int i = 0; i < 5; ++i)
-    fast = fast && (a->tex[i].w & (a->tex[i].w - 1)) == 0 && (a->tex[i].h & (a->tex[i].h - 1)) == 0 && a->tex[i].w == a->tex[0].w &&
-           a->tex[i].h == a->tex[0].h && a->tex[i].levels == a->tex[0].levels;
 
   uint32_t* counters = fw.counters;
   uint32_t* next_counters = fw.next_counters;
@@ -529,7 +546,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   for (int i = 0; i < 5; ++i) in.tex[i] = a->tex[i];
   in.irr = a->irr; in.pre = a->pre; in.sky = a->sky;
   in.irr_b = apr->irr_b.cube; in.pre_b = apr->pre_b.cube; in.sky_b = apr->sky_b.cube;
-  in.lut = a->d_lut; in.lut_pair = apr->d_lut_pair; in.lut_size = a->lut_size;
+  in.lut = a->d_lut; in.lut_quad = apr->d_lut_quad; in.atlas = fast ? apr->d_atlas : nullptr; in.lut_size = a->lut_size;
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
   if (msaa) launch_surface_msaa(s, dp, in, pr->d_srgb_lut, vis, c->d_tile_live, color, W, rows, fast);
   else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, fw.lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
@@ -650,7 +667,7 @@ int pbr_destroy(PbrContext* c) {
   free_dev(c->d_vsoa); free_dev(c->d_indices); free_dev(c->d_inst_model); free_dev(c->d_inst_normal);
   for (auto& t : c->d_tex) free_dev(t);
   free_dev(c->d_hdr); free_dev(c->d_hdr_rgb); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
-  { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); free_dev(pr->d_lut_pair); }
+  { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); free_dev(pr->d_lut_quad); free_dev(pr->d_atlas); }
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
   free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
   free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
@@ -765,6 +782,7 @@ int pbr_upload_texture(PbrContext* c, int slot, const uint8_t* rgba8, int32_t w,
   HIP_TRY(c, up);
   HIP_TRY(c, hipGetLastError());
   c->tex_has_mips[slot] = t.levels > 1;
+  priv_of(c)->atlas_dirty = true;
   return PBR_OK;
 }
 
@@ -951,7 +969,7 @@ int pbr_ibl_brdf_lut(PbrContext* c, int32_t size) {
     c->lut_size = size;
   }
   launch_brdf_lut(c->stream, c->d_lut, size);
-  priv_of(c)->lut_pair_dirty = true;
+  priv_of(c)->lut_quad_dirty = true;
   HIP_TRY(c, hipGetLastError());
   return PBR_OK;
 }
@@ -1027,7 +1045,7 @@ int pbr_ibl_device_ptr(PbrContext* c, int which, void** dev_ptr, size_t* total_b
   PbrContextPrivate* pr = priv_of(c);
   if (which == PBR_MAP_SKYBOX) pr->sky_b.dirty = true;
   if (which == PBR_MAP_IRRADIANCE) pr->irr_b.dirty = true;
-  if (which == PBR_MAP_BRDF_LUT) pr->lut_pair_dirty = true;
+  if (which == PBR_MAP_BRDF_LUT) pr->lut_quad_dirty = true;
   if (which == PBR_MAP_PREFILTER) pr->pre_b.dirty = true;
   *dev_ptr = p;
   if (total_bytes) *total_bytes = bytes;

@@ -200,7 +200,14 @@ struct ResolveInputs {
   DevCube irr, pre, sky;
   DevCubeRgb irr_b, pre_b, sky_b;   // the same maps with a one-texel border per face (level l: [6][n+2][n+2], n = size >> l), rgb only
   const uint16_t* lut;
-  const uint32_t* lut_pair;      // the table's two used channels per texel, A | B << 16 (half bits): half the footprint of the rgba16f table
+  // The table's two used channels (A | B << 16, half bits) of the four texels of the bilinear footprint whose upper
+  // left texel is (x, y), with the repeat wrap applied: (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1).  One load per lookup.
+  const uint4* lut_quad;
+  // The five material textures of one size interleaved texel by texel, in the blocked order and with the level
+  // offsets of tex[0]: x = albedo, y = emissive, z = normal (whole texels), w = occlusion.r | metallicRoughness.g << 8 |
+  // metallicRoughness.b << 16.  One 16-byte load fetches what fs_main reads of a texel position from all five
+  // (null when the textures differ in size).
+  const uint4* atlas;
   int32_t lut_size;
 };
 // covered pixels; the rasteriser has already written the skybox colour of the background pixels
@@ -215,6 +222,8 @@ void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInput
                          uint8_t* rgba8, int W, int rows, bool fast);
 int surface_fast_blocks_per_cu();
 void launch_cube_border(hipStream_t s, DevCube src, int level, float* dst_level);   // dst: [6][n+2][n+2][3]
-void launch_lut_pair(hipStream_t s, const uint16_t* lut_rgba16f, uint32_t* pair, int size);
+void launch_lut_quad(hipStream_t s, const uint16_t* lut_rgba16f, uint4* quad, int size);
+// interleaves five texture chains of `texels` texels each (slot order of PBR_TEX_*) into the layout of ResolveInputs::atlas
+void launch_material_atlas(hipStream_t s, const uint32_t* const chains[5], uint4* atlas, size_t texels);
 // pixels with at least one covered sample
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n_pixels, int samples, uint32_t* covered);

@@ -633,8 +633,6 @@ PBR_DEV V3 decode_fast(const uint32_t t[4], const Footprint& f, const float* s_s
   return r;
 }
 
-PBR_DEV void load4(const uint32_t* base, const Footprint& f, uint32_t t[4]) { t[0] = base[f.o00]; t[1] = base[f.o10]; t[2] = base[f.o01]; t[3] = base[f.o11]; }
-
 // shader.wgsl:101-105, :111, :148 from an already fetched normal-map sample.
 PBR_DEV void tbn_reflect(const FrameParams* p, const V3& T, const Varyings& v, V3 ns, V3& normal, V3& view_dir, V3& R) {
   const V3 tn = v3(ns.x * 2.0f - 1.0f, ns.y * 2.0f - 1.0f, ns.z * 2.0f - 1.0f);
@@ -684,16 +682,21 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
 
   // second dependent load: every material texel of this pixel, and the normal-map texels of the helper pixels
   const Footprint fp = footprint_fast(tx0, level, f.uv.x, f.uv.y);
-  uint32_t t_nrm[4], t_mr[4], t_alb[4], t_emi[4], t_occ[4], t_h0[4], t_h1[4], t_h2[4];
-  load4(in.tex[PBR_TEX_NORMAL].base, fp, t_nrm);
-  load4(in.tex[PBR_TEX_METALLIC_ROUGHNESS].base, fp, t_mr);
-  load4(in.tex[PBR_TEX_ALBEDO].base, fp, t_alb);
-  load4(in.tex[PBR_TEX_EMISSIVE].base, fp, t_emi);
-  load4(in.tex[PBR_TEX_OCCLUSION].base, fp, t_occ);
+  // (one 16-byte load per tap from the interleaved copy of the five textures)
+  uint32_t t_nrm[4], t_orm[4], t_alb[4], t_emi[4], t_h0[4], t_h1[4], t_h2[4];
+  {
+    const uint4 m0 = in.atlas[fp.o00], m1 = in.atlas[fp.o10], m2 = in.atlas[fp.o01], m3 = in.atlas[fp.o11];
+    t_alb[0] = m0.x; t_alb[1] = m1.x; t_alb[2] = m2.x; t_alb[3] = m3.x;
+    t_emi[0] = m0.y; t_emi[1] = m1.y; t_emi[2] = m2.y; t_emi[3] = m3.y;
+    t_nrm[0] = m0.z; t_nrm[1] = m1.z; t_nrm[2] = m2.z; t_nrm[3] = m3.z;
+    t_orm[0] = m0.w; t_orm[1] = m1.w; t_orm[2] = m2.w; t_orm[3] = m3.w;
+  }
   Footprint fp0 = fp, fp1 = fp, fp2 = fp;
   if constexpr (!UNIFORM) {
     fp0 = footprint_fast(tx0, level, h0.uv.x, h0.uv.y); fp1 = footprint_fast(tx0, level, h1.uv.x, h1.uv.y); fp2 = footprint_fast(tx0, level, h2.uv.x, h2.uv.y);
-    load4(in.tex[PBR_TEX_NORMAL].base, fp0, t_h0); load4(in.tex[PBR_TEX_NORMAL].base, fp1, t_h1); load4(in.tex[PBR_TEX_NORMAL].base, fp2, t_h2);
+    const uint32_t* nrm = reinterpret_cast<const uint32_t*>(in.atlas) + 2;   // the normal-map texel of atlas entry i is dword 4 i + 2
+    auto normals = [&](const Footprint& f, uint32_t t[4]) { t[0] = nrm[4u * f.o00]; t[1] = nrm[4u * f.o10]; t[2] = nrm[4u * f.o01]; t[3] = nrm[4u * f.o11]; };
+    normals(fp0, t_h0); normals(fp1, t_h1); normals(fp2, t_h2);
   }
 
   V3 normal, view_dir, R, R0, R1, R2;
@@ -707,8 +710,8 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
     tbn_reflect(p, T, h2, decode_fast<false>(t_h2, fp2, s_srgb), n_, v_, R2);
   }
   const float ndotv = fmaxf(dot(normal, view_dir), 0.0f);
-  const V3 mr = decode_fast<false>(t_mr, fp, s_srgb);
-  const float metalness = mr.z, roughness = mr.y;
+  const V3 orm = decode_fast<false>(t_orm, fp, s_srgb);   // occlusion.r, metallicRoughness.g, metallicRoughness.b
+  const float metalness = orm.z, roughness = orm.y;
 
   // third dependent load: irradiance (one level), prefilter (two levels of the implicit LOD), BRDF table
   float lambda = cube_lambda(in.pre.size, R, R1 - R0, R2 - R0);
@@ -723,20 +726,20 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   const int ls = in.lut_size;
   const float lu = ndotv * (float)ls - 0.5f, lv = roughness * (float)ls - 0.5f;
   const float lfu = floorf(lu), lfv = floorf(lv), la = lu - lfu, lb = lv - lfv;
-  int lx0 = (int)lfu, ly0 = (int)lfv, lx1 = lx0 + 1, ly1 = ly0 + 1;
+  int lx0 = (int)lfu, ly0 = (int)lfv;
   const bool bad_lut = isnan(lu) || isnan(lv);
-  if ((ls & (ls - 1)) == 0) { lx0 &= ls - 1; lx1 &= ls - 1; ly0 &= ls - 1; ly1 &= ls - 1; }
-  else { lx0 = ((lx0 % ls) + ls) % ls; lx1 = ((lx1 % ls) + ls) % ls; ly0 = ((ly0 % ls) + ls) % ls; ly1 = ((ly1 % ls) + ls) % ls; }
-  if (bad_lut) { lx0 = lx1 = ly0 = ly1 = 0; }
+  if ((ls & (ls - 1)) == 0) { lx0 &= ls - 1; ly0 &= ls - 1; }
+  else { lx0 = ((lx0 % ls) + ls) % ls; ly0 = ((ly0 % ls) + ls) % ls; }
+  if (bad_lut) { lx0 = ly0 = 0; }
   Rgb ti[4], ta[4], tb[4];
   cube_load4(in.irr_b.base, fi, ti); cube_load4(in.pre_b.base, fa, ta); cube_load4(in.pre_b.base, fb, tb);
-  const uint32_t* lt = in.lut_pair;
-  const uint32_t u00 = lt[(uint32_t)ly0 * ls + lx0], u10 = lt[(uint32_t)ly0 * ls + lx1], u01 = lt[(uint32_t)ly1 * ls + lx0], u11 = lt[(uint32_t)ly1 * ls + lx1];
+  const uint4 lq = in.lut_quad[(uint32_t)ly0 * ls + lx0];   // the footprint's four texels, wrapped (see ResolveInputs::lut_quad)
+  const uint32_t u00 = lq.x, u10 = lq.y, u01 = lq.z, u11 = lq.w;
 
   // the rest of fs_main (shader.wgsl:95, :108-159)
   const P3 albedo = p3(decode_fast<true>(t_alb, fp, s_srgb));
   const P3 emissive = p3(decode_fast<true>(t_emi, fp, s_srgb)) * p3(p->u.emissive_factor[0], p->u.emissive_factor[1], p->u.emissive_factor[2]);
-  const float occlusion = decode_fast<false>(t_occ, fp, s_srgb).x;
+  const float occlusion = orm.x;
   const float om = 1.0f - metalness;
   const P3 f0c = p3s(0.04f * om) + albedo * metalness;
   const V3 f0 = v3(f0c.rg.x, f0c.rg.y, f0c.b);
@@ -825,6 +828,12 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
 #endif
 constexpr int kSurfaceThreads = PBR_SURFACE_THREADS;
 constexpr int kXcds = 8;
+#ifdef PBR_SURFACE_TRACE
+// Diagnostic build only (make TRACE=1): every wavefront of the surface kernel's last launch leaves the 100 MHz
+// timestamps of its start and of the end of each of its items; pbr_debug_surface_trace copies them out.
+constexpr int kTraceSlots = 16;
+__device__ unsigned long long g_surface_trace[1024 * 16][kTraceSlots];
+#endif
 __global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(const FrameParams frame_params, ResolveInputs in,
                                                                                const float* __restrict__ srgb_lut, uint32_t* __restrict__ rgba8,
                                                                                QuadLists lists, const uint32_t* __restrict__ counters) {
@@ -842,6 +851,11 @@ __global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(c
   const uint32_t u_begin = (uint32_t)((unsigned long long)items_uniform * v / nv), u_end = (uint32_t)((unsigned long long)items_uniform * (v + 1) / nv);
   const uint32_t own_mixed = m_end - m_begin, own = own_mixed + (u_end - u_begin);
   const int lane = threadIdx.x & 63;
+#ifdef PBR_SURFACE_TRACE
+  unsigned long long* trace = g_surface_trace[(blockIdx.x * (kSurfaceThreads / 64) + (threadIdx.x >> 6)) % (1024 * 16)];
+  int trace_n = 2;
+  if (lane == 0) { trace[0] = wall_clock64(); trace[1] = ((unsigned long long)blockIdx.x << 32) | (own_mixed << 16) | own; }
+#endif
   for (;;) {
     uint32_t k = 0;
     if (lane == 0) k = atomicAdd(&s_next, 1u);
@@ -859,7 +873,14 @@ __global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(c
       const uint32_t id = reinterpret_cast<const uint32_t*>(lists.mixed_ids)[(live ? q : 0u) * 4u + (uint32_t)(lane & 3)];
       surface_fast_quad<false>(p, in, s_srgb, rgba8, (int)(pos & 0xffffu) * 2, p->y0 + (int)(pos >> 16) * 2, id, live);
     }
+#ifdef PBR_SURFACE_TRACE
+    if (lane == 0 && trace_n < kTraceSlots) trace[trace_n] = (wall_clock64() << 1) | (k >= own_mixed ? 1ull : 0ull);
+    ++trace_n;
+#endif
   }
+#ifdef PBR_SURFACE_TRACE
+  if (lane == 0) for (int i = trace_n; i < kTraceSlots; ++i) trace[i] = 0ull;
+#endif
 }
 
 // The same work lists for every other sampler: the general per-lane shading (address modes, nearest / linear
@@ -927,10 +948,23 @@ __global__ void __launch_bounds__(256) cube_border_kernel(DevCube src, int level
   dst[3 * (size_t)idx] = out.x; dst[3 * (size_t)idx + 1] = out.y; dst[3 * (size_t)idx + 2] = out.z;
 }
 
-// The two channels fs_main reads from the rgba16f BRDF table (shader.wgsl:150-151), packed for the resolve.
-__global__ void __launch_bounds__(256) lut_pair_kernel(const uint16_t* __restrict__ lut, uint32_t* __restrict__ pair, int n) {
+// The two channels fs_main reads from the rgba16f BRDF table (shader.wgsl:150-151), packed for the resolve: per texel
+// the whole bilinear footprint that starts there (see ResolveInputs::lut_quad).
+__global__ void __launch_bounds__(256) lut_quad_kernel(const uint16_t* __restrict__ lut, uint4* __restrict__ quad, int size) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) { const ushort4 t = reinterpret_cast<const ushort4*>(lut)[i]; pair[i] = (uint32_t)t.x | ((uint32_t)t.y << 16); }
+  if (i >= size * size) return;
+  const int x = i % size, y = i / size, x1 = (x + 1) % size, y1 = (y + 1) % size;
+  auto pair = [&](int xx, int yy) { const size_t t = (size_t)yy * size + xx; return (uint32_t)lut[4 * t] | ((uint32_t)lut[4 * t + 1] << 16); };
+  quad[i] = make_uint4(pair(x, y), pair(x1, y), pair(x, y1), pair(x1, y1));
+}
+
+__global__ void __launch_bounds__(256) material_atlas_kernel(const uint32_t* __restrict__ albedo, const uint32_t* __restrict__ emissive,
+                                                             const uint32_t* __restrict__ normal, const uint32_t* __restrict__ mr,
+                                                             const uint32_t* __restrict__ occlusion, uint4* __restrict__ atlas, size_t texels) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= texels) return;
+  const uint32_t m = mr[i], o = occlusion[i];
+  atlas[i] = make_uint4(albedo[i], emissive[i], normal[i], (o & 255u) | (((m >> 8) & 0xffffu) << 8));
 }
 
 // Number of covered pixels, for the frame statistics only: one atomic per 16384 pixels (a single
@@ -988,8 +1022,13 @@ void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInput
   else hipLaunchKernelGGL(resolve_surface_msaa_kernel<false>, grid, dim3(256), 0, s, p, in, srgb_lut, vis4, tile_live, out);
 }
 
-void launch_lut_pair(hipStream_t s, const uint16_t* lut_rgba16f, uint32_t* pair, int size) {
-  hipLaunchKernelGGL(lut_pair_kernel, dim3((unsigned)(((size_t)size * size + 255) / 256)), dim3(256), 0, s, lut_rgba16f, pair, size * size);
+void launch_lut_quad(hipStream_t s, const uint16_t* lut_rgba16f, uint4* quad, int size) {
+  hipLaunchKernelGGL(lut_quad_kernel, dim3((unsigned)(((size_t)size * size + 255) / 256)), dim3(256), 0, s, lut_rgba16f, quad, size);
+}
+
+void launch_material_atlas(hipStream_t s, const uint32_t* const chains[5], uint4* atlas, size_t texels) {
+  hipLaunchKernelGGL(material_atlas_kernel, dim3((unsigned)((texels + 255) / 256)), dim3(256), 0, s, chains[PBR_TEX_ALBEDO], chains[PBR_TEX_EMISSIVE],
+                     chains[PBR_TEX_NORMAL], chains[PBR_TEX_METALLIC_ROUGHNESS], chains[PBR_TEX_OCCLUSION], atlas, texels);
 }
 
 void launch_cube_border(hipStream_t s, DevCube src, int level, float* dst_level) {
@@ -1000,3 +1039,9 @@ void launch_cube_border(hipStream_t s, DevCube src, int level, float* dst_level)
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, int samples, uint32_t* covered) {
   hipLaunchKernelGGL(count_covered_kernel, dim3((unsigned)((n + 16383) / 16384)), dim3(256), 0, s, vis, n, samples, covered);
 }
+
+#ifdef PBR_SURFACE_TRACE
+extern "C" int pbr_debug_surface_trace(unsigned long long* out, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_surface_trace), bytes < sizeof(g_surface_trace) ? bytes : sizeof(g_surface_trace));
+}
+#endif
