@@ -1,65 +1,58 @@
-// Cheap evaluations of the two inverse trigonometric functions of the equirect mapping
-// (equirectangular.wgsl:68, prefiltermap.wgsl:157-163).  The prefilter only needs the PIXEL a direction falls into,
-// floor(u * w) and floor(v * h); these polynomials are within a known distance of the library's atan2f / asinf, so
-// they decide the pixel whenever the scaled coordinate is farther than that distance from an integer, and the
-// library functions are called only for the few samples that are not (see equirect_pixel_fast).  The result is
-// the library's pixel in every case.
+// The two inverse trigonometric functions of the equirect mapping (equirectangular.wgsl:68, prefiltermap.wgsl:157-163)
+// as the device library evaluates them, operation for operation, with the library's special-case handling split off:
+// atan2_regular / asin_regular give the bits of atan2f / asinf for every argument equirect_regular accepts, and the
+// caller evaluates the library functions themselves for the rest (both arguments zero, infinities, NaN, magnitudes
+// where the library's scaled division and a plain multiply by the reciprocal could round differently).  The library
+// computes min / max through a division protected against overflow by frexp / ldexp scaling; for magnitudes within
+// 2^+-60 that quotient is the product with the hardware reciprocal, bit for bit, because both round the same
+// significand product.  scripts/equirect_exact_check.hip compares the bits over 2^33 directions.
 #pragma once
 #include "devmath.h"
 
-// Largest distance, in radians, seen between these functions and the device library's over 2^33 directions (a
-// quarter of them hugging the poles, the seam and the axes; scripts/equirect_approx_check.hip) is 2.4e-7 for atan2
-// and 1.2e-7 for asin (one unit in the last place of the largest results, in both cases); the guards are twice that.
-#define EQUIRECT_ATAN2_GUARD 5.0e-7f
-#define EQUIRECT_ASIN_GUARD 2.5e-7f
+#define EQUIRECT_K(bits) __uint_as_float(bits##u)
 
-// atan2(y, x): octant reduction to a = min / max in [0, 1], odd minimax polynomial of degree 15 (1.4e-7 in f32).
-PBR_DEV float atan2_fast(float y, float x) {
+// |x| and |y| both ordinary and not both zero: the arguments atan2_regular covers.
+PBR_DEV bool equirect_regular(float y, float x) {
+  // 2^-60 <= max(|x|, |y|) < 2^60 as one unsigned comparison of the exponent field (infinities and NaN lie above)
+  const uint32_t m = __float_as_uint(fmaxf(fabsf(x), fabsf(y)));
+  return m - 0x21800000u < 0x3c000000u;
+}
+
+PBR_DEV float atan2_regular(float y, float x) {
+#pragma clang fp contract(off)
   const float ax = fabsf(x), ay = fabsf(y);
-  const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-  const float a = mn * rcp_fast(mx);   // 0 / 0 gives NaN, which the caller's guard sends to the library path
+  const float u = fmaxf(ax, ay), v = fminf(ax, ay);
+  const float a = v * rcp_fast(u);
   const float s = a * a;
-  float p = -0.004054485820233822f;
-  p = fmaf(p, s, 0.021862655878067017f);
-  p = fmaf(p, s, -0.05591187998652458f);
-  p = fmaf(p, s, 0.09642163664102554f);
-  p = fmaf(p, s, -0.13908615708351135f);
-  p = fmaf(p, s, 0.19946563243865967f);
-  p = fmaf(p, s, -0.33329859375953674f);
-  p = fmaf(p, s, 0.9999993443489075f);
-  float r = a * p;
-  r = ay > ax ? 1.57079632679489662f - r : r;
-  r = x < 0.0f ? 3.14159265358979324f - r : r;
+  float p = fmaf(s, EQUIRECT_K(0x3b2d2a58), EQUIRECT_K(0xbc7a590c));
+  p = fmaf(s, p, EQUIRECT_K(0x3d29fb3f));
+  p = fmaf(s, p, EQUIRECT_K(0xbd97d4d7));
+  p = fmaf(s, p, EQUIRECT_K(0x3dd931b2));
+  p = fmaf(s, p, EQUIRECT_K(0xbe1160e6));
+  p = fmaf(s, p, EQUIRECT_K(0x3e4cb8bf));
+  p = fmaf(s, p, EQUIRECT_K(0xbeaaaa62));
+  p = s * p;
+  float r = fmaf(a, p, a);
+  r = ay > ax ? EQUIRECT_K(0x3fc90fdb) - r : r;
+  r = x < 0.0f ? EQUIRECT_K(0x40490fdb) - r : r;
   return copysignf(r, y);
 }
 
-// asin(y), |y| <= 1: y + y^3 R(y^2) for |y| <= 0.5, pi/2 - 2 asin(sqrt((1 - |y|) / 2)) beyond.
-PBR_DEV float asin_fast(float y) {
+// |y| <= 1 (the caller clamps).
+PBR_DEV float asin_regular(float y) {
+#pragma clang fp contract(off)
   const float ay = fabsf(y);
-  const bool big = ay > 0.5f;
-  const float s = big ? fmaf(ay, -0.5f, 0.5f) : ay * ay;
-  const float r = big ? __builtin_amdgcn_sqrtf(s) : ay;
-  float p = 0.043763067573308945f;
-  p = fmaf(p, s, 0.023142263293266296f);
-  p = fmaf(p, s, 0.04570779576897621f);
-  p = fmaf(p, s, 0.07493077218532562f);
-  p = fmaf(p, s, 0.16666822135448456f);
-  const float t = fmaf(r * s, p, r);
-  return copysignf(big ? fmaf(t, -2.0f, 1.57079632679489662f) : t, y);
-}
-
-// Pixel coordinates (before truncation) of direction d in an equirect level of w x h pixels, both powers of two:
-// tu = u * w, tv = v * h with (u, v) as in equirectangular.wgsl:68.  Returns false when a coordinate is so close to
-// an integer that the cheap functions cannot tell on which side the library's result lies (or is NaN); the caller
-// then evaluates the library expression.  When it returns true, (int)tu and (int)tv are the library's pixel.
-// The guard: the functions' distance to the library's, scaled like the coordinate, plus the rounding of the
-// multiply-add that forms u and v on either path (two half-ulps of a number below 1).
-PBR_DEV bool equirect_pixel_fast(float dx, float dy, float dz, float w, float h, float& tu, float& tv) {
-  const float u = fmaf(atan2_fast(dz, dx), 0.1591f, 0.5f);
-  const float v = fmaf(asin_fast(fminf(fmaxf(dy, -1.0f), 1.0f)), 0.3183f, 0.5f);
-  tu = u * w; tv = v * h;
-  const float gu = w * (EQUIRECT_ATAN2_GUARD * 0.1591f + 1.2e-7f), gv = h * (EQUIRECT_ASIN_GUARD * 0.3183f + 1.2e-7f);
-  const float fu = __builtin_amdgcn_fractf(tu), fv = __builtin_amdgcn_fractf(tv);
-  // written so that a NaN fails the test
-  return fabsf(fu - 0.5f) < 0.5f - gu && fabsf(fv - 0.5f) < 0.5f - gv;
+  const bool small = ay < 0.5f;   // (one predicate for both selections; the library tests ay >= 0.5 here, the same for every number)
+  const float s = small ? y * y : fmaf(ay, -0.5f, 0.5f);
+  float p = fmaf(s, EQUIRECT_K(0x3d1c21a7), EQUIRECT_K(0x3c5fc5da));
+  p = fmaf(s, p, EQUIRECT_K(0x3d034c3c));
+  p = fmaf(s, p, EQUIRECT_K(0x3d3641b1));
+  p = fmaf(s, p, EQUIRECT_K(0x3d999bc8));
+  p = fmaf(s, p, EQUIRECT_K(0x3e2aaaac));
+  const float q = s * p;
+  const float root = __builtin_amdgcn_sqrtf(s);
+  const float t = fmaf(root, q, root);
+  const float far = EQUIRECT_K(0x3fc90fdb) - (t + t);
+  const float near = fmaf(ay, q, ay);
+  return copysignf(small ? near : far, y);
 }

@@ -178,10 +178,37 @@ PBR_DEV V3 sample_to_world(const V3& T, const V3& B, const V3& N, float lx, floa
 // GGX prefilter of one cube level.  SPLIT lanes share a texel and stride the sample table; the
 // table holds, per kept sample, the light direction in the texel's tangent frame, the two source
 // levels and their blend — all independent of the texel because N = V (prefiltermap.wgsl:124-126).
+//
+// The loop is bound by vector-instruction issue, and on this chip an f32 add / multiply / fma whose operands are all
+// vector registers or constants issues at twice the rate of one that reads a scalar register.  With one texel per
+// lane (SPLIT == 1) the sample is the same in every lane and would arrive in scalar registers; its floating-point
+// fields are therefore staged in LDS and read back as a broadcast into vector registers (LDS reads issue beside the
+// vector ALU), and only the level numbers, which feed scalar address arithmetic, come through scalar loads.
+constexpr int kPrefilterWideThreads = 1024;   // workgroup of the one-texel-per-lane variant: sixteen 8 x 8 texel blocks share one staged table
+
+// min(max(x, 0), top) as the one median instruction it is
+PBR_DEV int clamp_to(int x, int top) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(x), "s"(top));
+  return r;
+}
+
 template <int SPLIT, bool POW2>
-__global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples,
-                                                        float total_weight, float4* __restrict__ out, int size, long long first, long long count) {
-  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(SPLIT == 1 ? kPrefilterWideThreads : 256)
+prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples, float total_weight, float4* __restrict__ out, int size,
+                 long long first, long long count) {
+  constexpr int kThreads = SPLIT == 1 ? kPrefilterWideThreads : 256;
+  // per sample {lx, ly, lz, wa}, {wc, width and height of source level l0 as floats, unused}
+  __shared__ float4 s_table[SPLIT == 1 ? 2 * PBR_PREFILTER_SAMPLES : 1];
+  if constexpr (SPLIT == 1) {
+    for (int i = threadIdx.x; i < n_samples; i += kThreads) {
+      const PrefilterSample s = samples[i];
+      s_table[2 * i] = make_float4(s.lx, s.ly, s.lz, s.wa);
+      s_table[2 * i + 1] = make_float4(s.wc, (float)max(1, hdr.w >> s.l0), (float)max(1, hdr.h >> s.l0), 0.0f);
+    }
+    __syncthreads();
+  }
+  const long long gid = (long long)blockIdx.x * kThreads + threadIdx.x;
   long long t;
   int sub;
   bool live;
@@ -214,38 +241,49 @@ __global__ void __launch_bounds__(256) prefilter_kernel(DevEquirect hdr, const P
   const V3 B = cross(N, T);
   float r = 0, g = 0, b = 0;
   const int log2w = 31 - __clz(hdr.w);   // used when POW2: width a power of two, at least the height, so every level's width is 1 << (log2w - level)
+  // the two scale factors of equirectangular.wgsl:2 held in vector registers (see the note on issue rates above)
+  float inv_atan_x = INV_ATAN_X, inv_atan_y = INV_ATAN_Y;
+  asm volatile("" : "+v"(inv_atan_x), "+v"(inv_atan_y));
   for (int i = sub; i < n_samples; i += SPLIT) {
-    const PrefilterSample s = samples[i];
-    const V3 L = sample_to_world(T, B, N, s.lx, s.ly, s.lz);
-    const int w0 = max(1, hdr.w >> s.l0), h0 = max(1, hdr.h >> s.l0), w1 = max(1, hdr.w >> s.l1), h1 = max(1, hdr.h >> s.l1);
-    float tu = 0.0f, tv = 0.0f, u = 0.0f, v = 0.0f;   // u, v: set (and used) on the library path only
-    bool decided = false;
-    // Only the pixel matters: polynomials decide it unless a coordinate is within their error of a pixel boundary in
-    // some lane (about one wavefront-sample in eight at the finest source level used); then the library functions
-    // the shader's atan2 / asin stand for are evaluated, so the pixel is theirs in every case.
-    if constexpr (POW2) decided = equirect_pixel_fast(L.x, L.y, L.z, (float)w0, (float)h0, tu, tv);
-    if (__builtin_amdgcn_ballot_w64(!decided) != 0ull) {
-      u = atan2f(L.z, L.x) * INV_ATAN_X + 0.5f;
-      v = asinf(fminf(fmaxf(L.y, -1.0f), 1.0f)) * INV_ATAN_Y + 0.5f;
-      tu = u * (float)w0; tv = v * (float)h0;
+    float lx, ly, lz, wa, wc, w0f, h0f;
+    int l0, l1;
+    if constexpr (SPLIT == 1) {
+      const float4 dir = s_table[2 * i], rest = s_table[2 * i + 1];
+      lx = dir.x; ly = dir.y; lz = dir.z; wa = dir.w; wc = rest.x; w0f = rest.y; h0f = rest.z;
+      l0 = samples[i].l0; l1 = samples[i].l1;   // the same in every lane: scalar loads
+    } else {
+      const PrefilterSample s = samples[i];
+      lx = s.lx; ly = s.ly; lz = s.lz; wa = s.wa; wc = s.wc; l0 = s.l0; l1 = s.l1;
+      w0f = (float)max(1, hdr.w >> l0); h0f = (float)max(1, hdr.h >> l0);
     }
-    const int x0 = max(min((int)tu, w0 - 1), 0), y0 = max(min((int)tv, h0 - 1), 0);
-    int x1, y1;
-    uint32_t row0, row1;
+    const V3 L = sample_to_world(T, B, N, lx, ly, lz);
+    const int w0 = max(1, hdr.w >> l0), h0 = max(1, hdr.h >> l0), w1 = max(1, hdr.w >> l1), h1 = max(1, hdr.h >> l1);
+    // (u, v) of equirectangular.wgsl:68.  The two functions are the device library's, evaluated by their
+    // operation-for-operation restatements (equirect_math.h); the few arguments those do not cover - a direction
+    // along the Y axis, a NaN - go to the library itself, the whole wavefront with them.
+    const float yc = fminf(fmaxf(L.y, -1.0f), 1.0f);
+    float theta = atan2_regular(L.z, L.x);
+    if (__builtin_amdgcn_ballot_w64(!equirect_regular(L.z, L.x)) != 0ull) theta = atan2f(L.z, L.x);
+    const float u = fmaf(theta, inv_atan_x, 0.5f), v = fmaf(asin_regular(yc), inv_atan_y, 0.5f);
+    const float tu = u * w0f, tv = v * h0f;
+    int x0, y0, x1, y1;
+    uint32_t i0, i1;   // pixel index within the level
+    if constexpr (SPLIT == 1) { x0 = clamp_to((int)tu, w0 - 1); y0 = clamp_to((int)tv, h0 - 1); }
+    else { x0 = max(min((int)tu, w0 - 1), 0); y0 = max(min((int)tv, h0 - 1), 0); }
     if constexpr (POW2) {
       // power-of-two source: a level's size is the previous one's half, scaling u by it is exact, and the pixel
       // of the coarser level (l1 >= l0) is the finer level's pixel shifted down - the same integers as below
       // (and rows are a shift apart)
-      x1 = x0 >> (s.l1 - s.l0); y1 = y0 >> (s.l1 - s.l0);
-      row0 = (uint32_t)y0 << (log2w - s.l0); row1 = (uint32_t)y1 << (log2w - s.l1);
+      x1 = x0 >> (l1 - l0); y1 = y0 >> (l1 - l0);
+      i0 = ((uint32_t)y0 << (log2w - l0)) + (uint32_t)x0; i1 = ((uint32_t)y1 << (log2w - l1)) + (uint32_t)x1;
     } else {
-      x1 = max(min((int)(u * (float)w1), w1 - 1), 0); y1 = max(min((int)(v * (float)h1), h1 - 1), 0);   // not POW2: always the library path
-      row0 = (uint32_t)y0 * (uint32_t)w0; row1 = (uint32_t)y1 * (uint32_t)w1;
+      x1 = max(min((int)(u * (float)w1), w1 - 1), 0); y1 = max(min((int)(v * (float)h1), h1 - 1), 0);
+      i0 = (uint32_t)y0 * (uint32_t)w0 + (uint32_t)x0; i1 = (uint32_t)y1 * (uint32_t)w1 + (uint32_t)x1;
     }
-    const float* qa = hdr.rgb + 3 * (size_t)(hdr.off[s.l0] + row0 + (uint32_t)x0);
-    const float* qc = hdr.rgb + 3 * (size_t)(hdr.off[s.l1] + row1 + (uint32_t)x1);
+    // (the level's start is added to the pointer, where it is scalar arithmetic, not to the per-lane index)
+    const float* qa = hdr.rgb + 3 * (size_t)hdr.off[l0] + 3 * (size_t)i0;
+    const float* qc = hdr.rgb + 3 * (size_t)hdr.off[l1] + 3 * (size_t)i1;
     const V3 a = v3(qa[0], qa[1], qa[2]), c = v3(qc[0], qc[1], qc[2]);   // one 12-byte load each
-    const float wa = s.wa, wc = s.wc;
     r += a.x * wa + c.x * wc; g += a.y * wa + c.y * wc; b += a.z * wa + c.z * wc;
   }
 #pragma unroll
@@ -346,10 +384,11 @@ void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* sam
     // 8-row bands that hold the range, one wavefront per 8 x 8 block of texels
     const long long row0 = (first / level_size) & ~7ll, row1 = (first + count - 1) / level_size;
     const long long threads = ((row1 - row0) / 8 + 1) * ((level_size + 7) / 8) * 64;
-    if (pow2) hipLaunchKernelGGL((prefilter_kernel<1, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
-                                 out_level, level_size, (long long)first, (long long)count);
-    else hipLaunchKernelGGL((prefilter_kernel<1, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
-                            out_level, level_size, (long long)first, (long long)count);
+    const dim3 grid((unsigned)((threads + kPrefilterWideThreads - 1) / kPrefilterWideThreads)), block(kPrefilterWideThreads);
+    if (pow2) hipLaunchKernelGGL((prefilter_kernel<1, true>), grid, block, 0, s, hdr, samples, n_samples, total_weight, out_level, level_size, (long long)first,
+                                 (long long)count);
+    else hipLaunchKernelGGL((prefilter_kernel<1, false>), grid, block, 0, s, hdr, samples, n_samples, total_weight, out_level, level_size, (long long)first,
+                            (long long)count);
   } else if (level_texels >= (1 << 14)) {
     long long threads = count * 8;
     if (pow2) hipLaunchKernelGGL((prefilter_kernel<8, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,

@@ -995,6 +995,7 @@ static int general_blocks_per_cu() {
 int surface_fast_blocks_per_cu() {
   int blocks = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, resolve_surface_fast_kernel, kSurfaceThreads, 0) != hipSuccess || blocks < 1) blocks = 1;
+  if (getenv("PBR_SURFACE_BLOCKS_PER_CU")) blocks = std::max(1, atoi(getenv("PBR_SURFACE_BLOCKS_PER_CU")));
   return blocks;
 }
 
