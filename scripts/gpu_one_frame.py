@@ -1,4 +1,5 @@
-"""Renders a few 4K frames (for profilers): python scripts/gpu_one_frame.py [distance] [frames]"""
+"""Renders a few 4K frames (for profilers) and prints the per-stage event times of the last ones:
+python scripts/gpu_one_frame.py [distance] [frames]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,6 +10,11 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 r = pkg.Renderer(width=3840, height=2160, skybox_size=1024)
 r.init()
 r.camera.update_camera_distance((5.0 - dist) * 100.0, 0.0)
-for _ in range(frames):
+acc = {}
+for i in range(frames):
     _, st = r.draw_frame(want_stats=True)
-print("resolve ms", st.ms_resolve, "raster ms", st.ms_raster, "covered", st.covered_pixels)
+    if i >= frames // 2:
+        for name, _ in st._fields_:
+            if name.startswith("ms_"):
+                acc.setdefault(name, []).append(getattr(st, name))
+print({k: round(sum(v) / len(v) * 1000, 2) for k, v in acc.items()}, "us; covered", st.covered_pixels)

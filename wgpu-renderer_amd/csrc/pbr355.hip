@@ -22,8 +22,10 @@ constexpr size_t kOverflowCap = kSetupCap * 2 + (1u << 16);
 constexpr size_t kQuads = (size_t)PBR_STATIC_MAX_TILES * (PBR_TILE / 2) * (PBR_TILE / 2);
 constexpr size_t kCounters = 0;                                                                   // 16 x u32
 constexpr size_t kTileCount = align_up(kCounters + 16 * sizeof(uint32_t));                        // [tiles] u32
-constexpr size_t kZeroedBytes = align_up(kTileCount + PBR_STATIC_MAX_TILES * sizeof(uint32_t));   // cleared at the start of every call
-constexpr size_t kBins = kZeroedBytes;                                                            // [tiles][PBR_BIN_CAP] u32
+constexpr size_t kLiveInfo = align_up(kTileCount + PBR_STATIC_MAX_TILES * sizeof(uint32_t));      // [tiles] u64
+constexpr size_t kZeroedBytes = align_up(kLiveInfo + PBR_STATIC_MAX_TILES * sizeof(uint64_t));    // cleared at the start of every call
+constexpr size_t kLiveTiles = kZeroedBytes;                                                       // [kLiveCap] u32
+constexpr size_t kBins = align_up(kLiveTiles + PBR_LIVE_TILE_CAP * sizeof(uint32_t));             // [tiles][PBR_BIN_CAP] u32
 constexpr size_t kSetup = align_up(kBins + (size_t)PBR_STATIC_MAX_TILES * PBR_BIN_CAP * sizeof(uint32_t));
 constexpr size_t kOverflow = align_up(kSetup + kSetupCap * sizeof(SetupTri));
 constexpr size_t kRecords = align_up(kOverflow + kOverflowCap * sizeof(uint2));
@@ -272,6 +274,7 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int sample
   if ((size_t)n_tiles > c->tile_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_dev(c->d_tile_count); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
+    free_dev(c->d_live_info); free_dev(c->d_live_tiles);
     const size_t n_quads = (size_t)n_tiles * (PBR_TILE / 2) * (PBR_TILE / 2);
     HIP_TRY(c, hipMalloc(&c->quad_lists.uniform, sizeof(uint2) * n_quads));
     HIP_TRY(c, hipMalloc(&c->quad_lists.mixed_pos, sizeof(uint32_t) * n_quads));
@@ -280,6 +283,9 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int sample
     HIP_TRY(c, hipMalloc(&c->d_tile_live, sizeof(uint32_t) * n_tiles));
     HIP_TRY(c, hipMalloc(&c->d_bins, sizeof(uint32_t) * (size_t)n_tiles * PBR_BIN_CAP));
     HIP_TRY(c, hipMemset(c->d_tile_count, 0, sizeof(uint32_t) * n_tiles));   // kept clear from frame to frame by the raster kernel
+    HIP_TRY(c, hipMalloc(&c->d_live_info, sizeof(unsigned long long) * n_tiles));
+    HIP_TRY(c, hipMalloc(&c->d_live_tiles, sizeof(uint32_t) * PBR_LIVE_TILE_CAP));
+    HIP_TRY(c, hipMemset(c->d_live_info, 0, sizeof(unsigned long long) * n_tiles));   // serial 0: no frame
     c->tile_cap = n_tiles; grew = true;
   }
   const size_t npix = (size_t)W * rows;
@@ -372,6 +378,7 @@ struct FrameWork {
   SetupTri* setup; size_t setup_cap;
   TriRecord* records;
   uint32_t* tile_count; uint32_t* bins;
+  LiveTiles live;
   uint2* overflow; size_t overflow_cap;
   QuadLists lists;
   uint32_t* counters; uint32_t* next_counters;
@@ -430,6 +437,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     unsigned char* base = g_scratch_ptr[c->device];
     fw.counters = reinterpret_cast<uint32_t*>(base + kCounters); fw.next_counters = fw.counters + 8;
     fw.tile_count = reinterpret_cast<uint32_t*>(base + kTileCount);
+    fw.live = LiveTiles{reinterpret_cast<uint32_t*>(base + kLiveTiles), reinterpret_cast<unsigned long long*>(base + kLiveInfo), PBR_LIVE_TILE_CAP, 1ull};   // (the array was just cleared: any serial but 0)
     fw.bins = reinterpret_cast<uint32_t*>(base + kBins);
     fw.setup = reinterpret_cast<SetupTri*>(base + kSetup); fw.setup_cap = kSetupCap;
     fw.overflow = reinterpret_cast<uint2*>(base + kOverflow); fw.overflow_cap = kOverflowCap;
@@ -445,6 +453,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     rc = ensure_frame_buffers(c, W, rows, tiles_x * tiles_y, samples);
     if (rc) return rc;
     fw.setup = c->d_setup; fw.setup_cap = c->setup_cap; fw.records = c->d_records; fw.tile_count = c->d_tile_count; fw.bins = c->d_bins;
+    fw.live = LiveTiles{c->d_live_tiles, c->d_live_info, PBR_LIVE_TILE_CAP, ++c->live_serial};
     fw.overflow = c->d_overflow; fw.overflow_cap = c->overflow_cap; fw.lists = c->quad_lists;
     // two sets of append counters, used by alternate frames (the rasteriser re-arms the next frame's set)
     fw.counters = c->d_counters + 8 * pr->counter_set;
@@ -527,7 +536,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   const VertexSource source = {nullptr, a->d_vsoa, a->d_inst_model, a->d_inst_normal};
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
   launch_setup_and_bin(s, dp, source, a->d_indices, fw.setup, fw.records, (uint32_t)fw.setup_cap, fw.tile_count, fw.bins, fw.overflow,
-                       (uint32_t)fw.overflow_cap, counters, a->n_indices / 3, a->n_instances, sky_b);
+                       (uint32_t)fw.overflow_cap, counters, fw.live, a->n_indices / 3, a->n_instances, sky_b);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
   // the visibility buffer is only written when someone will read it: the caller (vis output) or the
@@ -535,10 +544,10 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   const bool write_vis = d_vis != nullptr || want_host_vis || timed;
   if (msaa)
     launch_raster_msaa(s, dp, fw.setup, fw.tile_count, fw.bins, fw.overflow, (uint32_t)fw.overflow_cap, vis, c->capture_depth ? c->d_depth : nullptr,
-                       counters, next_counters, c->d_tile_live, write_vis || c->capture_depth, tiles_x, tiles_y);
+                       counters, next_counters, c->d_tile_live, write_vis || c->capture_depth, tiles_x, tiles_y, fw.live);
   else
     launch_raster(s, dp, fw.setup, fw.tile_count, fw.bins, fw.overflow, (uint32_t)fw.overflow_cap, vis, (c->capture_depth && !static_memory) ? c->d_depth : nullptr,
-                  counters, next_counters, fw.lists, write_vis, apr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y);
+                  counters, next_counters, fw.lists, write_vis, apr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y, fw.live);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
 
   ResolveInputs in;
@@ -669,7 +678,7 @@ int pbr_destroy(PbrContext* c) {
   free_dev(c->d_hdr); free_dev(c->d_hdr_rgb); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
   { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); free_dev(pr->d_lut_quad); free_dev(pr->d_atlas); }
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
-  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
+  free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_live_info); free_dev(c->d_live_tiles); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
   free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
   free_dev(pr->d_srgb_lut);
   if (c->h_counters) (void)hipHostFree(c->h_counters);

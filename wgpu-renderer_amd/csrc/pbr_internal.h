@@ -12,6 +12,8 @@
 #define PBR_GUARD 8.0f            // guard band in units of w
 #define PBR_PREFILTER_SAMPLES 1024
 #define PBR_MAX_SHARDS 4096         // most shards the prefilter's texels can be cut into
+#define PBR_LIVE_TILE_CAP 256   // most tiles that the rasteriser starts ahead of the rest (see LiveTiles)
+#define PBR_DENSE_TILE_REFS 48   // a tile with more triangle references than this is one of them
 #define PBR_BIN_CAP 256           // triangle references a tile keeps in its own row before spilling to the overflow list
 
 // An rgba8 texture with its mip chain in one allocation.  Every level is stored in blocks of 8 x 4
@@ -149,6 +151,7 @@ struct PbrContext {
   SetupTri* d_setup = nullptr;    size_t setup_cap = 0;
   TriRecord* d_records = nullptr; size_t record_cap = 0;   // one per triangle of every instance
   uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0; uint32_t* d_tile_live = nullptr;   // [tiles], [tiles][PBR_BIN_CAP]
+  unsigned long long* d_live_info = nullptr; uint32_t* d_live_tiles = nullptr; unsigned long long live_serial = 0;   // see LiveTiles
   QuadLists quad_lists = {nullptr, nullptr, nullptr};                                  // work lists of the resolve, each [tiles * 256]
   uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
   size_t min_setup_cap = 0, min_overflow_cap = 0;         // raised when a frame overflowed one of the two
@@ -186,12 +189,18 @@ void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa,
 // where the setup kernel takes a triangle's vertices from: transformed vertices in memory (vout), or the
 // vertex streams, transformed on the fly (vsoa set, vout unused)
 struct VertexSource { const VertexOut* vout; const float* vsoa; const float* inst_model; const float* inst_normal; };
+// The fullest tiles (more than PBR_DENSE_TILE_REFS triangle references), listed by the set-up launch as each crosses
+// that mark, so that the rasteriser can start them before anything else - the frame waits for the fullest tile:
+// tiles[k] for k < min(count, cap), count = frame counter 4; info[tile] = serial << 16 | min(k + 1, 0xffff) with a
+// serial number no earlier frame on these arrays used (never 0), so entries of earlier frames read as "not listed"
+// without anyone clearing them.
+struct LiveTiles { uint32_t* tiles; unsigned long long* info; uint32_t cap; unsigned long long serial; };
 void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint32_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
-                          int n_tris, int n_instances, const SkyShare& share);
+                          const LiveTiles& live, int n_tris, int n_instances, const SkyShare& share);
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                    uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, const QuadLists& lists, bool write_vis,
-                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y);
+                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y, const LiveTiles& live);
 struct ResolveInputs {
   const TriRecord* records;
   const VertexOut* vout;
@@ -217,7 +226,7 @@ void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in
 // holds the skybox colour of every pixel and the resolve blends the shaded triangles over it by coverage.
 void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                         uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, uint32_t* tile_live,
-                        bool write_empty_tiles, int tiles_x, int tiles_y);
+                        bool write_empty_tiles, int tiles_x, int tiles_y, const LiveTiles& live);
 void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, const uint32_t* tile_live,
                          uint8_t* rgba8, int W, int rows, bool fast);
 int surface_fast_blocks_per_cu();

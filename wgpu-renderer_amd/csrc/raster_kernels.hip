@@ -109,12 +109,18 @@ struct BinTargets {
   uint32_t* tile_count; uint32_t* bins;
   uint2* overflow; uint32_t overflow_cap;
   uint32_t* counters;
+  LiveTiles live;
   TriRecord* records;
   // when vsoa is set the triangle's vertices are transformed here from the vertex streams (and vout is not read)
   const float* vsoa; const float* inst_model; const float* inst_normal;
 };
 
 PBR_DEV void bin_store(const BinTargets& bt, uint32_t tile, uint32_t pos, uint32_t slot) {
+  if (pos == PBR_DENSE_TILE_REFS) {   // the tile has just become one of the full ones: list it (see LiveTiles)
+    const uint32_t k = atomicAdd(&bt.counters[4], 1u);
+    if (k < bt.live.cap) bt.live.tiles[k] = tile;
+    bt.live.info[tile] = (bt.live.serial << 16) | (unsigned long long)min(k + 1u, 0xffffu);
+  }
   if (pos < PBR_BIN_CAP) bt.bins[(size_t)tile * PBR_BIN_CAP + pos] = slot;
   else {
     const uint32_t o = atomicAdd(&bt.counters[1], 1u);
@@ -296,21 +302,70 @@ PBR_DEV long long bcast64(long long v, int src_lane) {
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
-__global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_params, const SetupTri* __restrict__ setup,
+#ifdef PBR_SURFACE_TRACE
+// Diagnostic build only: per tile of the rasteriser's last launch the 100 MHz timestamps of its workgroup's start, of the
+// end of its triangle loop and of its end, and its number of bin entries; pbr_debug_raster_trace copies them out.
+__device__ unsigned long long g_raster_trace[32768][8];
+#define RASTER_TRACE(slot, value) do { if (tid == 0 && tile < 32768) g_raster_trace[tile][slot] = (value); } while (0)
+#else
+#define RASTER_TRACE(slot, value) do { } while (0)
+#endif
+
+constexpr int kRasterThreads = 256, kRasterWaves = kRasterThreads / 64;
+
+__global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParams frame_params, const SetupTri* __restrict__ setup,
                                                      uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
                                                      const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
                                                      float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters,
-                                                     QuadLists lists, int write_vis, DevCubeRgb sky, uint32_t* __restrict__ rgba8, int sky_from_tile) {
+                                                     QuadLists lists, int write_vis, DevCubeRgb sky, uint32_t* __restrict__ rgba8, int sky_from_tile,
+                                                     LiveTiles live, int listed_rows) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
-  __shared__ uint32_t s_pairs[4], s_base[2];
-  const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
+  __shared__ uint32_t s_pairs[kRasterWaves], s_base[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // The frame's append counters come in two sets used by alternate frames; this launch re-arms the set of
   // the next frame, which nothing is using (the previous frame, its last user, finished before this launch began).
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
-  const int px0 = blockIdx.x * PBR_TILE, py0 = p->y0 + blockIdx.y * PBR_TILE;   // tile origin in pixels
-  const uint32_t n = tile_count[tile];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[4] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
+  // The first rows of workgroups take the tiles the set-up launch listed as the fullest: the frame waits for
+  // those, so they must not queue behind thousands of skybox tiles (the fullest tile of the 4K benchmark frame used to
+  // start 7 us into the launch and end it at 38 us).  Every tile also has a workgroup of its own after those, which
+  // leaves at once if the tile was taken from the list.  Only the full tiles go first: all tiles with geometry at the
+  // head of every launch cost 4 us per frame with four frames in flight, whose rasterisers then hold the chip's
+  // wave slots with latency-bound loops at the same time.
+  // A listed tile's reference count is read by two workgroups, the one that rasterises it and the tile's own, in either
+  // order, and has to be zero again for the next frame: each marks its visit in the count's top bit, and the one that
+  // finds the mark already there is the second and does the clearing.
+  constexpr uint32_t kVisited = 0x80000000u;
+  // (the listed tiles' workgroups are whole rows of the grid ahead of the tiles' own rows, so that a tile's own
+  // workgroup finds its tile coordinates in its block index without a division)
+  int tile, tile_x, tile_y;
+  uint32_t n;
+  bool clear_count = true;
+  if ((int)blockIdx.y < listed_rows) {
+    const uint32_t k = blockIdx.y * gridDim.x + blockIdx.x;
+    if (k >= min(counters[4], live.cap)) return;
+    tile = (int)live.tiles[k];
+    tile_x = tile % p->tiles_x; tile_y = tile / p->tiles_x;
+    if (tid == 0) s_base[0] = atomicOr(&tile_count[tile], kVisited);
+    __syncthreads();
+    n = s_base[0] & ~kVisited;
+    clear_count = (s_base[0] & kVisited) != 0u;
+    __syncthreads();   // s_base is used again below
+  } else {
+    tile_x = (int)blockIdx.x; tile_y = (int)blockIdx.y - listed_rows;
+    tile = tile_y * p->tiles_x + tile_x;
+    n = tile_count[tile] & ~kVisited;
+    if (n > PBR_DENSE_TILE_REFS) {
+      const unsigned long long v = live.info[tile];
+      const uint32_t k = (uint32_t)(v & 0xffffu) - 1u;   // position in the list
+      if ((v >> 16) == live.serial && k < (uint32_t)listed_rows * gridDim.x && k < live.cap) {
+        if (tid == 0 && (atomicOr(&tile_count[tile], kVisited) & kVisited) != 0u) tile_count[tile] = 0u;
+        return;
+      }
+    }
+  }
+  const int px0 = tile_x * PBR_TILE, py0 = p->y0 + tile_y * PBR_TILE;   // tile origin in pixels
+  RASTER_TRACE(0, wall_clock64()); RASTER_TRACE(3, (unsigned long long)n);
   // the first PBR_BIN_CAP references sit in the tile's own row; a fuller tile also filters the shared overflow list
   const uint32_t n_row = min(n, (uint32_t)PBR_BIN_CAP);
   const uint32_t n_entries = n_row + (n > PBR_BIN_CAP ? min(counters[1], overflow_cap) : 0u);
@@ -318,10 +373,10 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
   const unsigned long long clear_key = (unsigned long long)depth_key(1.0f) << 32;   // depth clear 1.0, no triangle
 
   if (n != 0u) {
-    for (int i = tid; i < PBR_TILE * PBR_TILE; i += 256) s_key[i] = clear_key;
+    for (int i = tid; i < PBR_TILE * PBR_TILE; i += kRasterThreads) s_key[i] = clear_key;
     __syncthreads();
     const long long ox = (long long)px0 * 256 + 128, oy = (long long)py0 * 256 + 128;
-    for (uint32_t chunk = 0; chunk < n_entries; chunk += 256) {
+    for (uint32_t chunk = 0; chunk < n_entries; chunk += kRasterThreads) {
       // lane-parallel: fetch one triangle per lane and set it up against this tile.  Entry
       // chunk + 4*lane + wave goes to this lane, so a short bin is still spread over all four waves.
       bool keep = false;
@@ -329,7 +384,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
       int a0 = 0, a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0, tl = 0, box = 0;
       float z0 = 0, dz1 = 0, dz2 = 0, inv_area = 0;
       uint32_t id = 0;
-      const uint32_t entry = chunk + 4u * lane + wave;
+      const uint32_t entry = chunk + (uint32_t)kRasterWaves * lane + wave;
       uint32_t slot = 0xffffffffu;
       if (entry < n_row) slot = bins[(size_t)tile * PBR_BIN_CAP + entry];
       else if (entry < n_entries) { const uint2 pr = overflow[entry - n_row]; if (pr.x == (uint32_t)tile) slot = pr.y; }
@@ -372,6 +427,10 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
       }
       unsigned long long todo = __ballot(keep);
       const int lx = lane & 7, ly = lane >> 3;
+#ifdef PBR_SURFACE_TRACE
+      if (chunk == 0) { RASTER_TRACE(4, wall_clock64()); RASTER_TRACE(5, (unsigned long long)__popcll(todo)); }
+      unsigned long long trace_blocks = 0;
+#endif
       while (todo) {
         const int src = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -389,6 +448,9 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
           const int c1 = (int)bias1, c2 = (int)bias2;
           for (int yy = by0; yy <= by1; yy += 8)
             for (int xx = bx0; xx <= bx1; xx += 8) {
+#ifdef PBR_SURFACE_TRACE
+              ++trace_blocks;
+#endif
               const int x = xx + lx, y = yy + ly;
               if (x > bx1 || y > by1) continue;
               const int xs = x * 256, ys = y * 256;
@@ -415,10 +477,14 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
             }
         }
       }
+#ifdef PBR_SURFACE_TRACE
+      if (chunk == 0) { RASTER_TRACE(6, wall_clock64()); RASTER_TRACE(7, trace_blocks); }
+#endif
     }
     __syncthreads();
   }
-  if (tid == 0) tile_count[tile] = 0u;   // leave the bin counters clear for the next frame
+  if (tid == 0 && clear_count) tile_count[tile] = 0u;   // leave the bin counters clear for the next frame
+  RASTER_TRACE(1, wall_clock64());
 
   // write the tile out: thread t holds pixels 4t .. 4t+3 of the row-major tile
   const int ty = tid >> 3, tx = (tid & 7) * 4;
@@ -462,6 +528,7 @@ __global__ void __launch_bounds__(256) raster_kernel(const FrameParams frame_par
       }
     }
   }
+  RASTER_TRACE(2, wall_clock64());
   if (n == 0u) return;
 
   // Work lists for the shading resolve, one entry per 2x2 pixel quad that holds a covered pixel.  A quad
@@ -524,7 +591,7 @@ __global__ void __launch_bounds__(256) raster_msaa_kernel(const FrameParams fram
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE * 4];
   const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[4] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
   const int px0 = blockIdx.x * PBR_TILE, py0 = p->y0 + blockIdx.y * PBR_TILE;
   const uint32_t n = tile_count[tile];
   const uint32_t n_row = min(n, (uint32_t)PBR_BIN_CAP);
@@ -652,6 +719,12 @@ __global__ void __launch_bounds__(256) raster_msaa_kernel(const FrameParams fram
 
 }  // namespace
 
+#ifdef PBR_SURFACE_TRACE
+extern "C" int pbr_debug_raster_trace(unsigned long long* out, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_raster_trace), bytes < sizeof(g_raster_trace) ? bytes : sizeof(g_raster_trace));
+}
+#endif
+
 void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa, const float* inst_model, const float* inst_normal,
                          VertexOut* out, int n_verts, int n_instances, const SkyShare& share_in) {
   const int per_instance = (n_verts + 255) / 256;
@@ -663,12 +736,12 @@ void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa,
 
 void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint32_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
-                          int n_tris, int n_instances, const SkyShare& share_in) {
+                          const LiveTiles& live, int n_tris, int n_instances, const SkyShare& share_in) {
   // tile_count is zero on entry (the raster kernel of the previous frame clears it) and so are the
   // frame's append counters (re-armed by the raster kernel of the previous frame)
   BinTargets bt;
   bt.setup = setup; bt.setup_cap = setup_cap; bt.tile_count = tile_count; bt.bins = bins; bt.overflow = overflow; bt.overflow_cap = overflow_cap;
-  bt.counters = counters; bt.records = records;
+  bt.counters = counters; bt.live = live; bt.records = records;
   bt.vsoa = src.vsoa; bt.inst_model = src.inst_model; bt.inst_normal = src.inst_normal;
   const int per_instance = (n_tris + 255) / 256;
   SkyShare share = share_in;
@@ -678,14 +751,17 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSourc
 
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                    uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, const QuadLists& lists, bool write_vis,
-                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y) {
-  hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
-                     next_counters, lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile);
+                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y, const LiveTiles& live) {
+  static const int listed_cap = getenv("PBR_LISTED_BLOCKS") ? atoi(getenv("PBR_LISTED_BLOCKS")) : (int)PBR_LIVE_TILE_CAP;   // (measurements)
+  const int n_tiles = tiles_x * tiles_y, listed_blocks = std::min(n_tiles, std::min(listed_cap, (int)live.cap));
+  const int listed_rows = (listed_blocks + tiles_x - 1) / tiles_x;
+  hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, listed_rows + tiles_y), dim3(kRasterThreads), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis,
+                     depth, counters, next_counters, lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile, live, listed_rows);
 }
 
 void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                         uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, uint32_t* tile_live,
-                        bool write_empty_tiles, int tiles_x, int tiles_y) {
+                        bool write_empty_tiles, int tiles_x, int tiles_y, const LiveTiles& live) {
   hipLaunchKernelGGL(raster_msaa_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
                      next_counters, tile_live, write_empty_tiles ? 1 : 0);
 }
