@@ -465,6 +465,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   fp.u = *u;
   mat4_mul_host(u->projection, u->view, fp.pv);
   fp.W = W; fp.H = H; fp.y0 = y0; fp.y1 = y1; fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
+  fp.tiles_x_magic = (uint32_t)((0x100000000ull + (uint64_t)tiles_x - 1) / (uint64_t)tiles_x);
   fp.n_verts = a->n_verts; fp.n_tris = a->n_indices / 3; fp.n_instances = a->n_instances;
   fp.has_instance_mats = a->has_instance_mats ? 1 : 0;
   fp.msaa = msaa ? 1 : 0;
@@ -1135,7 +1136,7 @@ int pbr_debug_vertex_stage(PbrContext* c, const PbrFrameUniforms* u, float* clip
   FrameParams fp;
   fp.u = *u;
   mat4_mul_host(u->projection, u->view, fp.pv);
-  fp.W = 32; fp.H = 32; fp.y0 = 0; fp.y1 = 32; fp.tiles_x = 1; fp.tiles_y = 1;
+  fp.W = 32; fp.H = 32; fp.y0 = 0; fp.y1 = 32; fp.tiles_x = 1; fp.tiles_y = 1; fp.tiles_x_magic = 0u;   // (no skybox tiles ride in this launch)
   fp.n_verts = c->n_verts; fp.n_tris = c->n_indices / 3; fp.n_instances = c->n_instances; fp.has_instance_mats = c->has_instance_mats ? 1 : 0;
   fp.msaa = 0;
   fp.two_over_w = 2.0f / 32.0f; fp.two_over_h = 2.0f / 32.0f;

@@ -105,6 +105,7 @@ struct FrameParams {
   float pv[16];             // projection * view
   int32_t W, H, y0, y1;
   int32_t tiles_x, tiles_y; // tiles covering rows [y0,y1)
+  uint32_t tiles_x_magic;   // ceil(2^32 / tiles_x) for tiles_x > 1: tile / tiles_x == umulhi(tile, magic) for every tile index (tiles_x <= 512)
   int32_t n_verts, n_tris, n_instances;
   int32_t has_instance_mats;
   int32_t msaa;             // 1 = four samples per pixel (bit 16 of the sampler index, renderer.ts:1927-1932)

@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
     const uint32_t k = blockIdx.y * gridDim.x + blockIdx.x;
     if (k >= min(counters[4], live.cap)) return;
     tile = (int)live.tiles[k];
-    tile_x = tile % p->tiles_x; tile_y = tile / p->tiles_x;
+    tile_y = p->tiles_x == 1 ? tile : (int)__umulhi((uint32_t)tile, p->tiles_x_magic); tile_x = tile - tile_y * p->tiles_x;
     if (tid == 0) s_base[0] = atomicOr(&tile_count[tile], kVisited);
     __syncthreads();
     n = s_base[0] & ~kVisited;

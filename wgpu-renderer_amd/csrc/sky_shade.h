@@ -222,7 +222,8 @@ struct SkyShare {
 
 // Every pixel of tile `tile` gets the skybox colour (covered ones are overwritten by the surface pass).
 PBR_DEV void sky_tile(const FrameParams* __restrict__ p, const DevCubeRgb& sky, uint32_t* __restrict__ rgba8, int tile) {
-  const int tile_x = tile % p->tiles_x, tile_y = tile / p->tiles_x;
+  // (a division by a number only known at run time is some thirty dependent instructions at the head of every workgroup)
+  const int tile_y = p->tiles_x == 1 ? tile : (int)__umulhi((uint32_t)tile, p->tiles_x_magic), tile_x = tile - tile_y * p->tiles_x;
   const int x = tile_x * PBR_TILE + (threadIdx.x & 7) * 4, y = p->y0 + tile_y * PBR_TILE + (threadIdx.x >> 3);
   if (x >= p->W || y >= p->y1) return;
   uint32_t c[4];
