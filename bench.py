@@ -48,7 +48,11 @@ def _newest(*names):
 TRAFFIC_FILE = _newest("r02_traffic.json", "r01_traffic.json")   # PMC pass of scripts/gpu_traffic.sh over this same workload
 VALU_FILE = _newest("r02_valu.json", "r01_valu.json")            # SQ_INSTS_VALU per launch, from scripts/gpu_pmc_frame.sh
 FRAME_KERNELS = ["setup_kernel", "raster_kernel", "resolve_surface_fast_kernel"]
-SIMDS, PEAK_CLOCK_HZ, CYCLES_PER_VALU_INSTRUCTION = 1024, 2.4e9, 4.0   # one vector instruction per SIMD every four cycles (measured)
+# Vector instructions do not all cost the same issue time: plain f32 add / mul / fma and the simple integer operations
+# retire at about one per 2.3 cycles per SIMD, anything that reads a scalar register, converts, compares or selects at
+# one per 4, the transcendental unit's at one per 8 (scripts/valu_rate_probe.hip, profiles/r02_valu_issue_rates.jsonl);
+# VALU_FILE holds each kernel's mean over its compiled instruction mix.  4.0 is the fallback for a file without it.
+SIMDS, CUS, PEAK_CLOCK_HZ, CYCLES_PER_VALU_INSTRUCTION = 1024, 256, 2.4e9, 4.0
 
 
 def measured_traffic(kernel):
@@ -67,16 +71,26 @@ def measured_frame_traffic():
 
 
 def valu_issue(kernels, ms):
-    """Share of the chip's vector-instruction issue slots that `kernels` fill when they take `ms` per launch:
-    counted wave-instructions x 4 cycles / (1024 SIMDs x time x 2.4 GHz).  The frame kernels are priced against
-    HBM bandwidth because the task says so; this is the limit they actually run into."""
+    """Shares of the chip's vector-instruction issue time, L1 tag lookups (one per compute unit per cycle) and
+    texture-address-unit time that `kernels` use when they take `ms` per launch, from the counters of VALU_FILE and the
+    live time, at the peak clock.  The frame kernels are priced against HBM bandwidth because the task says so; these
+    are the units they actually keep busy, and none of them is saturated: the kernels are bound by the latency of
+    their dependent load rounds at the few waves per SIMD their registers allow."""
     try:
         with open(VALU_FILE) as f:
             table = json.load(f)
         n = sum(float(table[k]["valu_wave_instructions"]) for k in kernels)
+        cycles = sum(float(table[k]["valu_wave_instructions"]) * float(table[k].get("issue_cycles_per_instruction", CYCLES_PER_VALU_INSTRUCTION)) for k in kernels)
     except (OSError, KeyError, ValueError):
         return None
-    return {"wave_instructions": n, "frac": n * CYCLES_PER_VALU_INSTRUCTION / (SIMDS * ms * 1e-3 * PEAK_CLOCK_HZ)}
+    clock_cycles = ms * 1e-3 * PEAK_CLOCK_HZ
+    out = {"wave_instructions": n, "issue_cycles_per_instruction": cycles / n, "frac": cycles / (SIMDS * clock_cycles)}
+    try:
+        out["l1_tag_lookup_frac"] = sum(float(table[k]["l1_tag_lookups"]) for k in kernels) / (CUS * clock_cycles)
+        out["texture_address_unit_frac"] = sum(float(table[k]["texture_address_busy_cycles"]) for k in kernels) / (CUS * clock_cycles)
+    except KeyError:
+        pass
+    return out
 
 
 def parse_args(argv=None):
@@ -331,7 +345,7 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
             # kernel shares the chip with the other frames' kernels and its event-to-event time is longer than a step
             "roofline": {"bound": "hbm", "kernel": "resolve_surface_fast_kernel", "launch_ms": iso_ms, "achieved": iso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": iso_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("resolve_surface_fast_kernel"), "algorithmic_bytes": surf_bytes,
-                         "bound_measured": "valu_issue", "valu_issue": issue_one,
+                         "bound_measured": "latency of dependent load rounds at four waves per SIMD; busiest unit: vector issue", "valu_issue": issue_one,
                          "in_flight": {"ms": surf_ms, "achieved": in_flight_gbs, "frac": in_flight_gbs / HBM_PEAK_GBS,
                                        "note": "event-to-event time of the kernel inside the timed region, stretched by the other frames in flight"}},
             "frame_roofline": {"bound": "hbm", "kernels": "all kernels of one frame (setup + sky, raster + sky, surface); wall time per frame with the configured frames in flight",
@@ -341,7 +355,7 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
                                "note": "algorithmic_bytes is the nominal figure of the survey's model: it counts 8 B per pixel of visibility-buffer write + read that the "
                                        "timed path does not perform (the resolve works from quad lists) and one rgba32f texel per sky pixel that a magnified cube never "
                                        "fetches; traffic is what the L2s' memory-side counters measured per frame",
-                               "bound_measured": "valu_issue", "valu_issue": issue_frame},
+                               "bound_measured": "latency (set-up, rasteriser) and vector issue (skybox, surface); no unit saturated", "valu_issue": issue_frame},
         }
     return r, lanes, result
 
@@ -439,7 +453,7 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
                      "reference_samples": texels * 1024, "reference_gsamples_per_s": texels * 1024 / (ms * 1e-3) / 1e9,
                      # work executed: roughness 0 collapses to one sample per texel and samples with N.L <= 0 contribute nothing
                      "executed_samples": executed, "executed_gsamples_per_s": executed / (ms * 1e-3) / 1e9, "kept_samples_per_level": kept,
-                     "bound_measured": "texture-address path (two 16-byte gathers per sample); see profiles/r02_prefilter_counters.txt"})
+                     "bound_measured": "two 12-byte gathers per sample: texture-address units 75 % busy, every gather misses L1 (5 L2 requests per wavefront load); see profiles/r02_prefilter_counters.txt"})
     except Exception as exc:                             # the frame benchmark above stands on its own
         info["error"] = f"{type(exc).__name__}: {exc}"
     if rank == 0 and result is not None:

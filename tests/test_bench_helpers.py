@@ -27,8 +27,11 @@ def test_committed_instruction_counts_are_readable():
     assert one is not None and frame is not None
     assert 0.2 < one["frac"] < 1.0 and 0.2 < frame["frac"] < 1.0
     assert frame["wave_instructions"] > one["wave_instructions"] > 1e6
-    # frac = instructions x 4 cycles / (1024 SIMDs x time x 2.4 GHz)
-    assert abs(one["frac"] - one["wave_instructions"] * 4 / (1024 * 0.037e-3 * 2.4e9)) < 1e-9
+    # frac = instructions x mean issue cycles of the kernel's instruction mix / (1024 SIMDs x time x 2.4 GHz)
+    assert 2.3 <= one["issue_cycles_per_instruction"] <= 4.0
+    assert abs(one["frac"] - one["wave_instructions"] * one["issue_cycles_per_instruction"] / (1024 * 0.037e-3 * 2.4e9)) < 1e-9
+    # the other two units a gather-heavy kernel can saturate: L1 tag lookups and the texture-address units, per compute unit
+    assert 0.05 < one["l1_tag_lookup_frac"] < 1.0 and 0.05 < one["texture_address_unit_frac"] < 1.0
     assert b.valu_issue(["no_such_kernel"], 0.05) is None
 
 
