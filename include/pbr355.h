@@ -183,8 +183,9 @@ int pbr_draw_frame_device(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w,
  * every GPU the library runs on holds until the process ends, so the call makes no hipMalloc / hipFree and the
  * frame has to fit it: single-sample pipeline only (PBR_E_UNSUPPORTED with bit 16 of sampler_index), at most
  * 2048 tiles of 32 x 32 pixels in rows [y0,y1) (e.g. 1920 x 1080) and at most 32768 triangles over all instances
- * (PBR_E_ARG beyond either).  The lookup copies the library derives from the IBL maps must exist already:
- * PBR_E_STATE until one pbr_draw_frame_device / pbr_draw_frame has run after the last IBL call.  Every call on
+ * (PBR_E_ARG beyond either).  The lookup copies the library derives from the IBL maps and from the material
+ * textures must exist already: PBR_E_STATE until one pbr_draw_frame_device / pbr_draw_frame has run after the last
+ * IBL or texture call.  Every call on
  * one GPU, from whichever context, uses the same array: calls that overlap on one GPU race, so order them on
  * one stream (or with events).  A capacity overflow is reported by the next pbr_synchronize. */
 int pbr_draw_frame_static(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1, void* d_rgba8);
