@@ -232,7 +232,7 @@ def test_prefilter_shards_carry_equal_cost(pkg):
 
     def factors(m):   # (side faces, +-Y faces)
         r = m / (mips - 1)
-        return (1.0, 1.0) if m == 0 else (1.0, 1.44) if r <= 0.17 else (1.27, 1.41) if r <= 0.28 else (1.37, 1.44)
+        return (1.0, 1.0) if m == 0 else (1.0, 1.60) if r <= 0.17 else (1.32, 1.87) if r <= 0.28 else (1.37, 1.44)
 
     segments = []     # (first texel, texel count, cost per texel, samples per texel) of every face of every level
     first = 0
@@ -252,7 +252,7 @@ def test_prefilter_shards_carry_equal_cost(pkg):
         costs = [load(b, e, 2) for b, e in zip(cuts, cuts[1:])]
         assert max(costs) / (sum(costs) / world) <= 1.02, (world, costs)
         samples = [load(b, e, 3) for b, e in zip(cuts, cuts[1:])]          # without the measured factors: still no idle shard
-        assert max(samples) / (sum(samples) / world) <= 1.35, (world, samples)
+        assert max(samples) / (sum(samples) / world) <= 1.45, (world, samples)
         assert [sh.prefilter_shard_texels(size, mips, r, world) for r in range(world)] == list(zip(cuts, cuts[1:]))
     # the reference's own size: five levels of 128^2
     for world in (2, 4, 8):

@@ -184,7 +184,9 @@ PBR_DEV V3 sample_to_world(const V3& T, const V3& B, const V3& N, float lx, floa
 // lane (SPLIT == 1) the sample is the same in every lane and would arrive in scalar registers; its floating-point
 // fields are therefore staged in LDS and read back as a broadcast into vector registers (LDS reads issue beside the
 // vector ALU), and only the level numbers, which feed scalar address arithmetic, come through scalar loads.
-constexpr int kPrefilterWideThreads = 1024;   // workgroup of the one-texel-per-lane variant: sixteen 8 x 8 texel blocks share one staged table
+// Workgroup of the one-texel-per-lane variant: sixteen 8 x 8 texel blocks share one staged table on the large levels;
+// a level of under a million texels would be too few such workgroups to fill the chip evenly and takes four blocks each.
+constexpr int kPrefilterWideThreads = 1024, kPrefilterNarrowThreads = 256;
 
 // min(max(x, 0), top) as the one median instruction it is
 PBR_DEV int clamp_to(int x, int top) {
@@ -193,11 +195,11 @@ PBR_DEV int clamp_to(int x, int top) {
   return r;
 }
 
-template <int SPLIT, bool POW2>
-__global__ void __launch_bounds__(SPLIT == 1 ? kPrefilterWideThreads : 256)
+template <int SPLIT, bool POW2, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS)
 prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples, float total_weight, float4* __restrict__ out, int size,
                  long long first, long long count) {
-  constexpr int kThreads = SPLIT == 1 ? kPrefilterWideThreads : 256;
+  constexpr int kThreads = THREADS;
   // per sample {lx, ly, lz, wa}, {wc, width and height of source level l0 as floats, unused}
   __shared__ float4 s_table[SPLIT == 1 ? 2 * PBR_PREFILTER_SAMPLES : 1];
   if constexpr (SPLIT == 1) {
@@ -384,11 +386,15 @@ void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* sam
     // 8-row bands that hold the range, one wavefront per 8 x 8 block of texels
     const long long row0 = (first / level_size) & ~7ll, row1 = (first + count - 1) / level_size;
     const long long threads = ((row1 - row0) / 8 + 1) * ((level_size + 7) / 8) * 64;
-    const dim3 grid((unsigned)((threads + kPrefilterWideThreads - 1) / kPrefilterWideThreads)), block(kPrefilterWideThreads);
-    if (pow2) hipLaunchKernelGGL((prefilter_kernel<1, true>), grid, block, 0, s, hdr, samples, n_samples, total_weight, out_level, level_size, (long long)first,
-                                 (long long)count);
-    else hipLaunchKernelGGL((prefilter_kernel<1, false>), grid, block, 0, s, hdr, samples, n_samples, total_weight, out_level, level_size, (long long)first,
-                            (long long)count);
+    const bool wide = level_texels >= (1 << 20);
+    const int per_group = wide ? kPrefilterWideThreads : kPrefilterNarrowThreads;
+    const dim3 grid((unsigned)((threads + per_group - 1) / per_group)), block(per_group);
+#define PBR_LAUNCH_PREFILTER(POW2_, THREADS_) \
+    hipLaunchKernelGGL((prefilter_kernel<1, POW2_, THREADS_>), grid, block, 0, s, hdr, samples, n_samples, total_weight, out_level, level_size, (long long)first, \
+                       (long long)count)
+    if (pow2) { if (wide) PBR_LAUNCH_PREFILTER(true, kPrefilterWideThreads); else PBR_LAUNCH_PREFILTER(true, kPrefilterNarrowThreads); }
+    else { if (wide) PBR_LAUNCH_PREFILTER(false, kPrefilterWideThreads); else PBR_LAUNCH_PREFILTER(false, kPrefilterNarrowThreads); }
+#undef PBR_LAUNCH_PREFILTER
   } else if (level_texels >= (1 << 14)) {
     long long threads = count * 8;
     if (pow2) hipLaunchKernelGGL((prefilter_kernel<8, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
