@@ -8,7 +8,7 @@ to the ranks, one process per GPU, no data-path collective: weak scaling.  Each 
 flight (default 4): one renderer context plus forks of it, which share ONE copy of the scene on the device and each
 own a stream and a colour target, take the rank's frames in turn, so the short latency-bound geometry kernels of
 one frame overlap the shading of the previous one.  `config.single_frame_ms` is the same frame with nothing else in
-flight.
+flight, on the context alone (its forks destroyed).
 
 `--mode strips`: the synthetic stress scene (10 x 10 instanced helmets, 7680x4320).  Every rank renders its
 even-aligned band of rows of every frame and the bands are gathered to rank 0 over RCCL: strong scaling of one frame.
@@ -16,8 +16,9 @@ even-aligned band of rows of every frame and the bands are gathered to rank 0 ov
 `python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run on 127.0.0.1).
 
 Prints ONE JSON line on rank 0.  `roofline` is for the surface-shading kernel: its launch duration measured with
-HIP events on the stream it runs on, with the chip to itself (`roofline.in_flight` has the same kernel inside the
-timed region, where the other frames' kernels stretch it).  `cpu_baseline` is the CPU oracle (a restatement of the
+HIP events on the stream it runs on, with the chip to itself, in the shape the library launches while the context
+has forks, i.e. the one of the timed region (`roofline.in_flight` has the same kernel inside the timed region, where
+the other frames' kernels stretch it; `roofline.lone_context` the shape a context without forks gets).  `cpu_baseline` is the CPU oracle (a restatement of the
 reference WGSL, not Dawn/SwiftShader) rendering frames of the same orbit on the host cores.
 """
 import argparse
@@ -279,14 +280,25 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
     pkg._lib.check(r._ctx, lib.pbr_profile_end(r._ctx, C.byref(frames), C.byref(surf_total), C.byref(span)))
     check_lanes(lanes)
 
-    # the dominant kernel with the chip to itself, and the frame with nothing else in flight: same frames, first context only
-    iso_frames, iso_total, iso_span = C.c_int32(), C.c_float(), C.c_float()
+    # the dominant kernel with the chip to itself: same frames, first context only, one at a time.  The library launches
+    # the surface kernel in one of two shapes, by whether the context shares its scene with forks (several frames in
+    # flight) or not; while the forks exist this is the shape that ran in the timed region.
+    def isolated(n):
+        frames_, total_, span_ = C.c_int32(), C.c_float(), C.c_float()
+        pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, n))
+        for i in range(args.warmup, args.warmup + n):
+            r.draw_frame_device(lanes[0][2].data_ptr(), uniforms=uniforms[i])
+        pkg._lib.check(r._ctx, lib.pbr_profile_end(r._ctx, C.byref(frames_), C.byref(total_), C.byref(span_)))
+        r.synchronize()
+        return frames_, total_, span_
+
     n_iso = min(args.steps, 20)
-    pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, n_iso))
-    for i in range(args.warmup, args.warmup + n_iso):
-        r.draw_frame_device(lanes[0][2].data_ptr(), uniforms=uniforms[i])
-    pkg._lib.check(r._ctx, lib.pbr_profile_end(r._ctx, C.byref(iso_frames), C.byref(iso_total), C.byref(iso_span)))
-    r.synchronize()
+    iso_frames, iso_total, iso_span = isolated(n_iso)
+    # the frame with nothing else in flight and no other context on the scene (config 2's "single frame"): the forks go first
+    for rr, _, _ in lanes[1:]:
+        rr.close()
+    lanes = lanes[:1]
+    lone_frames, lone_total, lone_span = isolated(n_iso)
 
     # coverage for the bandwidth model: sampled on a second pass over a tenth of the timed views (a
     # statistics call synchronises, so it stays out of the timed region)
@@ -315,7 +327,8 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
         in_flight_gbs = surf_bytes / (surf_ms * 1e-3) / 1e9
         iso_ms = iso_total.value / max(iso_frames.value, 1)
         iso_gbs = surf_bytes / (iso_ms * 1e-3) / 1e9
-        single_frame_ms = iso_span.value / max(iso_frames.value - 1, 1)
+        single_frame_ms = lone_span.value / max(lone_frames.value - 1, 1)
+        lone_ms = lone_total.value / max(lone_frames.value, 1)
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
         frame_traffic = measured_frame_traffic()
         issue_one = valu_issue(["resolve_surface_fast_kernel"], iso_ms)
@@ -339,13 +352,15 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
                        "frames_in_flight_per_gpu": K, "single_frame_ms": single_frame_ms,
                        "single_frame_mpix_per_s": npix / 1e6 / (single_frame_ms * 1e-3),
                        "covered_mpix_per_s_of_surface_kernel": c * npix / 1e6 / (iso_ms * 1e-3)},
-            "kernel_ms": {"resolve_surface_fast_kernel": iso_ms, "resolve_surface_fast_kernel_in_flight": surf_ms,
+            "kernel_ms": {"resolve_surface_fast_kernel": iso_ms, "resolve_surface_fast_kernel_in_flight": surf_ms, "resolve_surface_fast_kernel_lone_context": lone_ms,
                           "one_context_frame_to_frame": span.value / max(nf - 1, 1)},
             # the launch duration is the kernel's alone (nothing else on the chip); inside the timed region the same
             # kernel shares the chip with the other frames' kernels and its event-to-event time is longer than a step
             "roofline": {"bound": "hbm", "kernel": "resolve_surface_fast_kernel", "launch_ms": iso_ms, "achieved": iso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": iso_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("resolve_surface_fast_kernel"), "algorithmic_bytes": surf_bytes,
                          "bound_measured": "latency of dependent load rounds at four waves per SIMD; busiest unit: vector issue", "valu_issue": issue_one,
+                         "lone_context": {"launch_ms": lone_ms, "achieved": surf_bytes / (lone_ms * 1e-3) / 1e9, "frac": surf_bytes / (lone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "note": "the kernel's other shape (one 1024-thread workgroup per compute unit), which the library launches for a context without forks"},
                          "in_flight": {"ms": surf_ms, "achieved": in_flight_gbs, "frac": in_flight_gbs / HBM_PEAK_GBS,
                                        "note": "event-to-event time of the kernel inside the timed region, stretched by the other frames in flight"}},
             "frame_roofline": {"bound": "hbm", "kernels": "all kernels of one frame (setup + sky, raster + sky, surface); wall time per frame with the configured frames in flight",

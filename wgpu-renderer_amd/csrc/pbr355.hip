@@ -559,7 +559,8 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   in.lut = a->d_lut; in.lut_quad = apr->d_lut_quad; in.atlas = fast ? apr->d_atlas : nullptr; in.lut_size = a->lut_size;
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
   if (msaa) launch_surface_msaa(s, dp, in, pr->d_srgb_lut, vis, c->d_tile_live, color, W, rows, fast);
-  else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, fw.lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks);
+  // a context that shares its scene with forks is one of several frames in flight on this chip (see the two shapes of the surface kernel)
+  else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, fw.lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks, c->parent != nullptr || c->children > 0);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());

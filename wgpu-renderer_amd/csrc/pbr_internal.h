@@ -222,7 +222,7 @@ struct ResolveInputs {
 };
 // covered pixels; the rasteriser has already written the skybox colour of the background pixels
 void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    const QuadLists& lists, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks);
+                    const QuadLists& lists, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks, bool shared_chip);
 // The multisampled frame: vis (and depth, when wanted) hold four entries per pixel; the colour target already
 // holds the skybox colour of every pixel and the resolve blends the shaded triangles over it by coverage.
 void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,

@@ -823,10 +823,13 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
 // on neighbouring quads (L1) and an XCD's units on one eighth of the frame (its private L2).  The
 // waves of a workgroup claim its items one at a time from a counter in LDS, mixed quads (the
 // costlier ones) first, so they finish within one item of each other.
-#ifndef PBR_SURFACE_THREADS
-#define PBR_SURFACE_THREADS 1024   // four waves per SIMD: the kernel fits the 128 VGPRs that leaves it without spilling
-#endif
-constexpr int kSurfaceThreads = PBR_SURFACE_THREADS;
+// Two shapes of the same kernel.  One 1024-thread workgroup per compute unit (four waves per SIMD: the kernel fits the
+// 128 VGPRs that leaves it without spilling) is the faster one with the chip to itself: sixteen waves draw from one
+// pool of items.  But such a workgroup only starts on a compute unit with nothing else on it, so with several frames
+// in flight the surface kernels take turns at the whole chip; three 256-thread workgroups per compute unit find room
+// among the other frames' kernels and leave them a wave slot per SIMD (56.8 -> 55.1 us per 4K frame with four in
+// flight, 28.5 -> 31.5 us alone).  The host picks by whether the context shares its scene with forks.
+constexpr int kSurfaceThreads = 1024, kSurfaceSmallThreads = 256, kSurfaceSmallPerCu = 3;
 constexpr int kXcds = 8;
 #ifdef PBR_SURFACE_TRACE
 // Diagnostic build only (make TRACE=1): every wavefront of the surface kernel's last launch leaves the 100 MHz
@@ -834,13 +837,13 @@ constexpr int kXcds = 8;
 constexpr int kTraceSlots = 16;
 __device__ unsigned long long g_surface_trace[1024 * 16][kTraceSlots];
 #endif
-__global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(const FrameParams frame_params, ResolveInputs in,
-                                                                               const float* __restrict__ srgb_lut, uint32_t* __restrict__ rgba8,
-                                                                               QuadLists lists, const uint32_t* __restrict__ counters) {
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) resolve_surface_fast_kernel(const FrameParams frame_params, ResolveInputs in, const float* __restrict__ srgb_lut,
+                                                                       uint32_t* __restrict__ rgba8, QuadLists lists, const uint32_t* __restrict__ counters) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ float s_srgb[256];
   __shared__ uint32_t s_next;
-  if (threadIdx.x < 256) s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
+  for (int i = threadIdx.x; i < 256; i += THREADS) s_srgb[i] = srgb_lut[i];
   if (threadIdx.x == 0) s_next = 0u;
   __syncthreads();
   const uint32_t n_uniform = counters[6], n_mixed = counters[7];
@@ -852,7 +855,7 @@ __global__ void __launch_bounds__(kSurfaceThreads) resolve_surface_fast_kernel(c
   const uint32_t own_mixed = m_end - m_begin, own = own_mixed + (u_end - u_begin);
   const int lane = threadIdx.x & 63;
 #ifdef PBR_SURFACE_TRACE
-  unsigned long long* trace = g_surface_trace[(blockIdx.x * (kSurfaceThreads / 64) + (threadIdx.x >> 6)) % (1024 * 16)];
+  unsigned long long* trace = g_surface_trace[(blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)) % (1024 * 16)];
   int trace_n = 2;
   if (lane == 0) { trace[0] = wall_clock64(); trace[1] = ((unsigned long long)blockIdx.x << 32) | (own_mixed << 16) | own; }
 #endif
@@ -994,18 +997,22 @@ static int general_blocks_per_cu() {
 
 int surface_fast_blocks_per_cu() {
   int blocks = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, resolve_surface_fast_kernel, kSurfaceThreads, 0) != hipSuccess || blocks < 1) blocks = 1;
-  if (getenv("PBR_SURFACE_BLOCKS_PER_CU")) blocks = std::max(1, atoi(getenv("PBR_SURFACE_BLOCKS_PER_CU")));
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, resolve_surface_fast_kernel<kSurfaceThreads>, kSurfaceThreads, 0) != hipSuccess || blocks < 1) blocks = 1;
   return blocks;
 }
 
 void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in, const float* srgb_lut, const uint32_t* vis, uint8_t* rgba8,
-                    const QuadLists& lists, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks) {
+                    const QuadLists& lists, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks, bool shared_chip) {
   uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
   if (fast) {
     // as many workgroups as the chip holds at once, a multiple of the XCD count
     const int blocks = std::max(kXcds, resident_blocks / kXcds * kXcds);
-    hipLaunchKernelGGL(resolve_surface_fast_kernel, dim3(blocks), dim3(kSurfaceThreads), 0, s, p, in, srgb_lut, out, lists, counters);
+    if (shared_chip) {
+      const int small = std::max(kXcds, resident_blocks / std::max(1, surface_fast_blocks_per_cu()) * kSurfaceSmallPerCu / kXcds * kXcds);
+      hipLaunchKernelGGL(resolve_surface_fast_kernel<kSurfaceSmallThreads>, dim3(small), dim3(kSurfaceSmallThreads), 0, s, p, in, srgb_lut, out, lists, counters);
+    } else {
+      hipLaunchKernelGGL(resolve_surface_fast_kernel<kSurfaceThreads>, dim3(blocks), dim3(kSurfaceThreads), 0, s, p, in, srgb_lut, out, lists, counters);
+    }
   } else {
     const int per_cu = std::max(1, general_blocks_per_cu());
     const int blocks = std::max(kXcds, (resident_blocks / std::max(1, surface_fast_blocks_per_cu())) * per_cu / kXcds * kXcds);
