@@ -494,6 +494,15 @@ def test_4k_frame_properties(refsize):
         assert_frame_close(rgba[y0:y1], orgba, vis[y0:y1], ovis, "4K band", margin)
         srgba, svis = refsize.render_gpu(y0, y1)
         assert (srgba == rgba[y0:y1]).all() and (svis == vis[y0:y1]).all()
+        # the surface kernel's other launch shape (small workgroups, used while the scene is shared with a fork): the same bytes
+        fork = r.fork()
+        try:
+            shared, shared_vis = r.draw_frame(want_vis=True)
+            assert (shared == rgba).all() and (shared_vis == vis).all()
+            fork.width, fork.height, fork.camera = 3840, 2160, r.camera
+            assert (fork.draw_frame() == rgba).all()
+        finally:
+            fork.close()
         # sky rows: top band against the oracle
         orgba, ovis = refsize.render_oracle(0, 16)
         assert (ovis == 0).all() and (vis[:16] == 0).all()
