@@ -521,11 +521,14 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // latency-bound and leave the chip almost idle, so each carries a slice of the tiles as extra
   // workgroups; the rasteriser shades the rest (each workgroup its own tile).
   const int n_tiles = tiles_x * tiles_y;
-  // Skybox tiles that ride in the setup launch; the rasteriser's launch shades the rest.  With one frame at a time
-  // a little over half is best (the setup kernel is the longer wait); with three frames in flight, where the
-  // other frames fill that wait anyway, a third is (62.5 against 65.2 us per 4K frame).  PBR_SKY_SHARE_SETUP
-  // overrides it for measurements.
-  static const float share_setup = getenv("PBR_SKY_SHARE_SETUP") ? (float)atof(getenv("PBR_SKY_SHARE_SETUP")) : 0.35f;
+  // Skybox tiles that ride in the setup launch; the rasteriser's launch shades the rest.  With frames in flight a
+  // third is best (54.2 / 54.6 / 55.4 / 56.0 us per 4K frame at 0.35 / 0.45 / 0.55 / 0.65); one frame at a time does
+  // not care (88.6 - 90.0 us over the same range).  A measurement build sets another share with
+  // -DPBR_SKY_SHARE_SETUP=...; the library reads no environment variable.
+#ifndef PBR_SKY_SHARE_SETUP
+#define PBR_SKY_SHARE_SETUP 0.35f
+#endif
+  constexpr float share_setup = PBR_SKY_SHARE_SETUP;
   // A frame has no vertex launch: the setup kernel transforms each triangle's vertices from the streams itself
   // and leaves a shading record per triangle, which is all the resolve kernels read.
   // The multisampled resolve blends over the skybox colour, which therefore has to be complete before the

@@ -752,8 +752,7 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSourc
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                    uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, const QuadLists& lists, bool write_vis,
                    const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y, const LiveTiles& live) {
-  static const int listed_cap = getenv("PBR_LISTED_BLOCKS") ? atoi(getenv("PBR_LISTED_BLOCKS")) : (int)PBR_LIVE_TILE_CAP;   // (measurements)
-  const int n_tiles = tiles_x * tiles_y, listed_blocks = std::min(n_tiles, std::min(listed_cap, (int)live.cap));
+  const int n_tiles = tiles_x * tiles_y, listed_blocks = std::min(n_tiles, (int)live.cap);
   const int listed_rows = (listed_blocks + tiles_x - 1) / tiles_x;
   hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, listed_rows + tiles_y), dim3(kRasterThreads), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis,
                      depth, counters, next_counters, lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile, live, listed_rows);
