@@ -23,9 +23,9 @@ constexpr size_t kQuads = (size_t)PBR_STATIC_MAX_TILES * (PBR_TILE / 2) * (PBR_T
 constexpr size_t kCounters = 0;                                                                   // 16 x u32
 constexpr size_t kTileCount = align_up(kCounters + 16 * sizeof(uint32_t));                        // [tiles] u32
 constexpr size_t kLiveInfo = align_up(kTileCount + PBR_STATIC_MAX_TILES * sizeof(uint32_t));      // [tiles] u64
-constexpr size_t kZeroedBytes = align_up(kLiveInfo + PBR_STATIC_MAX_TILES * sizeof(uint64_t));    // cleared at the start of every call
-constexpr size_t kLiveTiles = kZeroedBytes;                                                       // [kLiveCap] u32
-constexpr size_t kBins = align_up(kLiveTiles + PBR_LIVE_TILE_CAP * sizeof(uint32_t));             // [tiles][PBR_BIN_CAP] u32
+constexpr size_t kLiveTiles = align_up(kLiveInfo + PBR_STATIC_MAX_TILES * sizeof(uint64_t));      // [PBR_LIVE_TILE_CAP] u64
+constexpr size_t kZeroedBytes = align_up(kLiveTiles + PBR_LIVE_TILE_CAP * sizeof(uint64_t));      // cleared at the start of every call
+constexpr size_t kBins = kZeroedBytes;                                                            // [tiles][PBR_BIN_CAP] u32
 constexpr size_t kSetup = align_up(kBins + (size_t)PBR_STATIC_MAX_TILES * PBR_BIN_CAP * sizeof(uint32_t));
 constexpr size_t kOverflow = align_up(kSetup + kSetupCap * sizeof(SetupTri));
 constexpr size_t kRecords = align_up(kOverflow + kOverflowCap * sizeof(uint2));
@@ -284,7 +284,8 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int sample
     HIP_TRY(c, hipMalloc(&c->d_bins, sizeof(uint32_t) * (size_t)n_tiles * PBR_BIN_CAP));
     HIP_TRY(c, hipMemset(c->d_tile_count, 0, sizeof(uint32_t) * n_tiles));   // kept clear from frame to frame by the raster kernel
     HIP_TRY(c, hipMalloc(&c->d_live_info, sizeof(unsigned long long) * n_tiles));
-    HIP_TRY(c, hipMalloc(&c->d_live_tiles, sizeof(uint32_t) * PBR_LIVE_TILE_CAP));
+    HIP_TRY(c, hipMalloc(&c->d_live_tiles, sizeof(unsigned long long) * PBR_LIVE_TILE_CAP));
+    HIP_TRY(c, hipMemset(c->d_live_tiles, 0, sizeof(unsigned long long) * PBR_LIVE_TILE_CAP));
     HIP_TRY(c, hipMemset(c->d_live_info, 0, sizeof(unsigned long long) * n_tiles));   // serial 0: no frame
     c->tile_cap = n_tiles; grew = true;
   }
@@ -437,7 +438,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     unsigned char* base = g_scratch_ptr[c->device];
     fw.counters = reinterpret_cast<uint32_t*>(base + kCounters); fw.next_counters = fw.counters + 8;
     fw.tile_count = reinterpret_cast<uint32_t*>(base + kTileCount);
-    fw.live = LiveTiles{reinterpret_cast<uint32_t*>(base + kLiveTiles), reinterpret_cast<unsigned long long*>(base + kLiveInfo), PBR_LIVE_TILE_CAP, 1ull};   // (the array was just cleared: any serial but 0)
+    fw.live = LiveTiles{reinterpret_cast<unsigned long long*>(base + kLiveTiles), reinterpret_cast<unsigned long long*>(base + kLiveInfo), PBR_LIVE_TILE_CAP, 1ull};   // (both arrays were just cleared: any serial but 0)
     fw.bins = reinterpret_cast<uint32_t*>(base + kBins);
     fw.setup = reinterpret_cast<SetupTri*>(base + kSetup); fw.setup_cap = kSetupCap;
     fw.overflow = reinterpret_cast<uint2*>(base + kOverflow); fw.overflow_cap = kOverflowCap;

@@ -152,7 +152,7 @@ struct PbrContext {
   SetupTri* d_setup = nullptr;    size_t setup_cap = 0;
   TriRecord* d_records = nullptr; size_t record_cap = 0;   // one per triangle of every instance
   uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0; uint32_t* d_tile_live = nullptr;   // [tiles], [tiles][PBR_BIN_CAP]
-  unsigned long long* d_live_info = nullptr; uint32_t* d_live_tiles = nullptr; unsigned long long live_serial = 0;   // see LiveTiles
+  unsigned long long* d_live_info = nullptr; unsigned long long* d_live_tiles = nullptr; unsigned long long live_serial = 0;   // see LiveTiles
   QuadLists quad_lists = {nullptr, nullptr, nullptr};                                  // work lists of the resolve, each [tiles * 256]
   uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
   size_t min_setup_cap = 0, min_overflow_cap = 0;         // raised when a frame overflowed one of the two
@@ -192,10 +192,11 @@ void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa,
 struct VertexSource { const VertexOut* vout; const float* vsoa; const float* inst_model; const float* inst_normal; };
 // The fullest tiles (more than PBR_DENSE_TILE_REFS triangle references), listed by the set-up launch as each crosses
 // that mark, so that the rasteriser can start them before anything else - the frame waits for the fullest tile:
-// tiles[k] for k < min(count, cap), count = frame counter 4; info[tile] = serial << 16 | min(k + 1, 0xffff) with a
-// serial number no earlier frame on these arrays used (never 0), so entries of earlier frames read as "not listed"
-// without anyone clearing them.
-struct LiveTiles { uint32_t* tiles; unsigned long long* info; uint32_t cap; unsigned long long serial; };
+// tiles[k] = serial << 24 | tile for the k-th tile to cross it (k from frame counter 4, k < cap); info[tile] =
+// serial << 16 | min(k + 1, 0xffff).  The serial number is one no earlier frame on these arrays used (never 0), so
+// entries of earlier frames read as "not listed" without anyone clearing them, and the rasteriser's workgroup k
+// learns from the one load of tiles[k] both whether there is a k-th tile and which.
+struct LiveTiles { unsigned long long* tiles; unsigned long long* info; uint32_t cap; unsigned long long serial; };
 void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint32_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           const LiveTiles& live, int n_tris, int n_instances, const SkyShare& share);

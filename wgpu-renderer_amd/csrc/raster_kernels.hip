@@ -115,10 +115,22 @@ struct BinTargets {
   const float* vsoa; const float* inst_model; const float* inst_normal;
 };
 
+#ifdef PBR_SURFACE_TRACE
+// Diagnostic build only: per workgroup of the set-up launch the 100 MHz timestamps of its start, of its triangles'
+// vertices being transformed, of its record and set-up stores being issued, of its binning and of its end;
+// pbr_debug_setup_trace copies them out.
+__device__ unsigned long long g_setup_trace[16384][8];
+#define SETUP_TRACE(slot) do { if ((threadIdx.x & 63) == 0 && (threadIdx.x >> 6) < 1 && blockIdx.x < 16384) g_setup_trace[blockIdx.x][slot] = wall_clock64(); } while (0)
+#define SETUP_TRACE_ANY(slot) do { const unsigned long long m_ = __ballot(1); if ((threadIdx.x >> 6) == 0 && (int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1 && blockIdx.x < 16384) g_setup_trace[blockIdx.x][slot] = wall_clock64(); } while (0)
+#else
+#define SETUP_TRACE_ANY(slot) do { } while (0)
+#define SETUP_TRACE(slot) do { } while (0)
+#endif
+
 PBR_DEV void bin_store(const BinTargets& bt, uint32_t tile, uint32_t pos, uint32_t slot) {
   if (pos == PBR_DENSE_TILE_REFS) {   // the tile has just become one of the full ones: list it (see LiveTiles)
     const uint32_t k = atomicAdd(&bt.counters[4], 1u);
-    if (k < bt.live.cap) bt.live.tiles[k] = tile;
+    if (k < bt.live.cap) bt.live.tiles[k] = (bt.live.serial << 24) | (unsigned long long)tile;
     bt.live.info[tile] = (bt.live.serial << 16) | (unsigned long long)min(k + 1u, 0xffffu);
   }
   if (pos < PBR_BIN_CAP) bt.bins[(size_t)tile * PBR_BIN_CAP + pos] = slot;
@@ -146,31 +158,135 @@ PBR_DEV void bin_four(const FrameParams* p, const BinTargets& bt, int tx0, int t
   for (int k = 0; k < 4; ++k) if (first + k < n) bin_store(bt, tile[k], pos[k], slot);
 }
 
-// A triangle whose bounding box spans more than sixteen tiles is not binned by its own thread (a
-// chain of dependent atomics); it is handed back so that the whole wavefront can bin it, one tile per lane.
-struct Deferred { uint32_t slot; int box; };   // box = tx0 | tx1 << 8 | ty0 << 16 | ty1 << 24, slot 0xffffffff = none
-
-PBR_DEV void emit_triangle(uint32_t id, float4 a, float4 b, float4 c, const FrameParams* p, const BinTargets& bt, Deferred* defer) {
+// Snaps, culls and bounds one (sub)triangle; false when nothing of it can be covered.
+PBR_DEV bool make_setup(uint32_t id, float4 a, float4 b, float4 c, const FrameParams* p, SetupTri& t, TileBox& box) {
   Snapped s0 = snap_vertex(a, p->W, p->H), s1 = snap_vertex(b, p->W, p->H), s2 = snap_vertex(c, p->W, p->H);
   const long long area2 = (long long)(s1.X - s0.X) * (s2.Y - s0.Y) - (long long)(s2.X - s0.X) * (s1.Y - s0.Y);
-  if (area2 >= 0) return;   // clockwise on screen or degenerate: culled (cullMode "back", frontFace "ccw")
-  SetupTri t;
+  if (area2 >= 0) return false;   // clockwise on screen or degenerate: culled (cullMode "back", frontFace "ccw")
   t.X[0] = s0.X; t.Y[0] = s0.Y; t.X[1] = s2.X; t.Y[1] = s2.Y; t.X[2] = s1.X; t.Y[2] = s1.Y;   // reorder: edge functions positive inside
   t.z0 = s0.z; t.dz1 = sub_rn(s2.z, s0.z); t.dz2 = sub_rn(s1.z, s0.z);
   t.inv_area = div_rn(1.0f, (float)(-area2));
   t.id = id; t.pad = 0;
+  return setup_bounds(t, p, box);
+}
+
+// A piece of a clipped triangle (rare): appended and binned by its own thread, one returning atomic after the other.
+PBR_DEV void emit_piece(uint32_t id, float4 a, float4 b, float4 c, const FrameParams* p, const BinTargets& bt) {
+  SetupTri t;
   TileBox box;
-  if (!setup_bounds(t, p, box)) return;
+  if (!make_setup(id, a, b, c, p, t, box)) return;
   const uint32_t slot = atomicAdd(&bt.counters[0], 1u);
   if (slot >= bt.setup_cap) { bt.counters[2] = 1u; return; }
   bt.setup[slot] = t;
-  const int n_tiles = (box.tx1 - box.tx0 + 1) * (box.ty1 - box.ty0 + 1);
-  if (defer && n_tiles > 16 && box.tx1 < 256 && box.ty1 < 256) {
-    defer->slot = slot; defer->box = box.tx0 | (box.tx1 << 8) | (box.ty0 << 16) | (box.ty1 << 24);
-    return;
-  }
-  const int bw = box.tx1 - box.tx0 + 1;
+  const int bw = box.tx1 - box.tx0 + 1, n_tiles = bw * (box.ty1 - box.ty0 + 1);
   for (int first = 0; first < n_tiles; first += 4) bin_four(p, bt, box.tx0, box.ty0, bw, n_tiles, first, slot);
+}
+
+// A whole triangle that survived culling, handed back by its thread so that its wavefront appends and bins its 64
+// triangles together (bin_wave).
+struct Pending { SetupTri t; TileBox box; int n_tiles; };   // n_tiles 0 = none
+
+// Scratch of one wavefront for bin_wave: reference counts and then positions of a 16 x 16 window of tiles, the list of
+// its tiles that have references, and the window's bounds.
+struct BinWindow { uint32_t count[256]; uint32_t next[256]; uint32_t list[256]; int bounds[4]; };
+
+PBR_DEV void wave_sync() {   // orders this wavefront's LDS traffic for the compiler; the hardware serves a wavefront's LDS instructions in order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Appends the wavefront's pending triangles to the setup list and references them from the tiles of their bounding
+// boxes.  An atomic on device memory that returns its value takes some 2 us here, and one per reference, from 64 lanes
+// whose triangles are neighbours and so count on the same few tiles, took 6 us a round (measured per workgroup with
+// the launch's timeline): the set-up launch spent more than half its time in them.  So the wavefront first counts
+// its references per tile in LDS (the tiles of its triangles nearly always fit a 16 x 16 window), then one lane per
+// tile adds the tile's count to the tile's counter in memory - a single round of atomics, every one on a different
+// address and in flight together with the one that reserves the setup slots - and the lanes take their positions from
+// LDS again.  The order of the references inside a tile's row differs from run to run, as it did before; the
+// rasteriser's result does not depend on it (nearest fragment, lowest triangle number on ties).
+PBR_DEV void bin_wave(const FrameParams* p, const BinTargets& bt, const Pending& pd, int lane, BinWindow* w) {
+  const bool have = pd.n_tiles > 0;
+  const unsigned long long have_mask = __ballot(have);
+  if (!have_mask) return;
+  const int leader = __ffsll((long long)have_mask) - 1;
+  // The setup slots of the wavefront's triangles: one atomic by one lane, waited for only where the slots are used, so
+  // that its round trip overlaps that of the tiles' atomics below.  The offset is hidden from the compiler: with an
+  // address it can prove uniform it would turn this into its own one-lane atomic followed at once by a wait and a
+  // broadcast.
+  uint32_t slot_base = 0u;
+  if (lane == leader) {
+    uint32_t zero = 0u;
+    asm volatile("" : "+v"(zero));
+    slot_base = atomicAdd(bt.counters + zero, (uint32_t)__popcll(have_mask));
+  }
+  const bool small = have && pd.n_tiles <= 16;
+  bool window = false;
+  int minx = 0, miny = 0;
+  if (__ballot(small)) {
+    reinterpret_cast<uint4*>(w->count)[lane] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < 4) w->bounds[lane] = lane < 2 ? 0x7fffffff : -1;
+    wave_sync();
+    if (small) { atomicMin(&w->bounds[0], pd.box.tx0); atomicMin(&w->bounds[1], pd.box.ty0); atomicMax(&w->bounds[2], pd.box.tx1); atomicMax(&w->bounds[3], pd.box.ty1); }
+    wave_sync();
+    minx = w->bounds[0]; miny = w->bounds[1];
+    window = w->bounds[2] - minx < 16 && w->bounds[3] - miny < 16;   // then (ty & 15, tx & 15) is a different entry for every tile
+  }
+  if (window) {
+    if (small)
+      for (int ty = pd.box.ty0; ty <= pd.box.ty1; ++ty)
+        for (int tx = pd.box.tx0; tx <= pd.box.tx1; ++tx) atomicAdd(&w->count[((ty & 15) << 4) | (tx & 15)], 1u);
+    wave_sync();
+    // the window's tiles that have references, gathered into a list so that one lane takes one tile and the atomics
+    // on the tiles' counters are a single instruction (four conditional ones, an entry each, wait for one another)
+    uint32_t count[4], at[4], total = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      count[k] = w->count[lane + 64 * k];
+      const unsigned long long m = __ballot(count[k] != 0u);
+      at[k] = total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      total += (uint32_t)__popcll(m);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (count[k]) w->list[at[k]] = (uint32_t)(lane + 64 * k) | (count[k] << 8);
+    wave_sync();
+    for (uint32_t j = (uint32_t)lane; j < total; j += 64u) {
+      const uint32_t item = w->list[j], entry = item & 255u;
+      const int tx = minx + ((((int)entry & 15) - minx) & 15), ty = miny + ((((int)entry >> 4) - miny) & 15);
+      w->next[entry] = atomicAdd(&bt.tile_count[ty * p->tiles_x + tx], item >> 8);
+    }
+    wave_sync();
+  }
+  SETUP_TRACE(5);
+  const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)slot_base, leader) + (uint32_t)__popcll(have_mask & ((1ull << lane) - 1ull));
+  const bool fits = slot < bt.setup_cap;
+  if (have && !fits) bt.counters[2] = 1u;   // the frame is drawn again with a larger list
+  if (have && fits) bt.setup[slot] = pd.t;
+  if (small) {
+    if (window) {
+      // the positions were counted above whether or not the triangle fits the list: one that does not leaves a
+      // reference to the list's first entry, which is memory the rasteriser may read, in a frame that is not kept
+      const uint32_t ref = fits ? slot : 0u;
+      for (int ty = pd.box.ty0; ty <= pd.box.ty1; ++ty)
+        for (int tx = pd.box.tx0; tx <= pd.box.tx1; ++tx)
+          bin_store(bt, (uint32_t)(ty * p->tiles_x + tx), atomicAdd(&w->next[((ty & 15) << 4) | (tx & 15)], 1u), ref);
+    } else if (fits) {
+      const int bw = pd.box.tx1 - pd.box.tx0 + 1;
+      for (int first = 0; first < pd.n_tiles; first += 4) bin_four(p, bt, pd.box.tx0, pd.box.ty0, bw, pd.n_tiles, first, slot);
+    }
+  }
+  SETUP_TRACE(6);
+  // triangles that span more than sixteen tiles: the whole wavefront bins each, one tile per lane
+  unsigned long long todo = __ballot(have && !small && fits);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const uint32_t s = (uint32_t)__builtin_amdgcn_readlane((int)slot, src);
+    const int tx0 = __builtin_amdgcn_readlane(pd.box.tx0, src), tx1 = __builtin_amdgcn_readlane(pd.box.tx1, src);
+    const int ty0 = __builtin_amdgcn_readlane(pd.box.ty0, src), ty1 = __builtin_amdgcn_readlane(pd.box.ty1, src);
+    const int bw = tx1 - tx0 + 1, n = bw * (ty1 - ty0 + 1);
+    for (int i = lane; i < n; i += 64) bin_reference(p, bt, (uint32_t)((ty0 + i / bw) * p->tiles_x + tx0 + i % bw), s);
+  }
 }
 
 // The triangle as the shading resolve wants it.  The snapped coordinates are the rasteriser's own (same
@@ -201,11 +317,12 @@ PBR_DEV void write_record(TriRecord* __restrict__ dst, const VertexOut& a, const
   if (!projective) { d[9] = ca; d[10] = cb; d[11] = cc; }   // only the homogeneous fallback of the resolve reads these
 }
 
-PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint32_t* indices, const BinTargets& bt, int inst, int t, int n_tris,
-                       Deferred* defer) {
+// The three vertices of triangle t of instance inst after the vertex stage: transformed here from the vertex streams,
+// or read from the vertex launch's output.
+PBR_DEV void fetch_triangle(const FrameParams* p, const VertexOut* vout, const uint32_t* indices, const BinTargets& bt, int inst, int t, VertexOut& va,
+                            VertexOut& vb, VertexOut& vc) {
   const size_t base = (size_t)inst * p->n_verts;
   const int ia = (int)indices[3 * (size_t)t], ib = (int)indices[3 * (size_t)t + 1], ic = (int)indices[3 * (size_t)t + 2];
-  VertexOut va, vb, vc;
   if (bt.vsoa) {
     VertexMatrices m;
     load_matrices(p, bt.inst_model, bt.inst_normal, inst, m);
@@ -214,7 +331,21 @@ PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint32
   } else {
     va = vout[base + ia]; vb = vout[base + ib]; vc = vout[base + ic];
   }
+}
+
+// One triangle per thread: trivial rejection, the shading record, and the triangle set up for the rasteriser in
+// `pending` (left empty when it is culled).  Returns true for a triangle that crosses a clip plane: its thread clips
+// it afterwards (clip_one), away from the common path, whose wavefronts then never wait for what only the clipping
+// leaves in flight.
+PBR_DEV bool setup_one(const FrameParams* p, const VertexOut* vout, const uint32_t* indices, const BinTargets& bt, int inst, int t, int n_tris,
+                       Pending& pending) {
+  VertexOut va, vb, vc;
+  fetch_triangle(p, vout, indices, bt, inst, t, va, vb, vc);
   const float4 a = va.clip, b = vb.clip, c = vc.clip;
+#ifdef PBR_SURFACE_TRACE
+  asm volatile("" :: "v"(a.x), "v"(b.x), "v"(c.x));
+#endif
+  SETUP_TRACE(1);
   const uint32_t id = (uint32_t)inst * (uint32_t)n_tris + (uint32_t)t;
   const float4 v[3] = {a, b, c};
   bool inside_all = true;
@@ -223,21 +354,30 @@ PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint32
     int outside = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) outside += plane_dist(pl, v[k]) < 0.0f;
-    if (outside == 3) return;
+    if (outside == 3) return false;
     if (outside) inside_all = false;
   }
   {
     int l = 0, r = 0, bt_ = 0, tp = 0;
 #pragma unroll
     for (int k = 0; k < 3; ++k) { l += v[k].x < -v[k].w; r += v[k].x > v[k].w; bt_ += v[k].y < -v[k].w; tp += v[k].y > v[k].w; }
-    if (l == 3 || r == 3 || bt_ == 3 || tp == 3) return;   // beside the viewport: no pixel centre can be covered
+    if (l == 3 || r == 3 || bt_ == 3 || tp == 3) return false;   // beside the viewport: no pixel centre can be covered
   }
   write_record(bt.records + id, va, vb, vc, p->W, p->H);
-  if (inside_all) { emit_triangle(id, a, b, c, p, bt, defer); return; }
-  // Rare path: Sutherland-Hodgman against the six planes, then a fan from the first vertex.
+  SETUP_TRACE(2);
+  if (!inside_all) return true;
+  if (make_setup(id, a, b, c, p, pending.t, pending.box)) pending.n_tiles = (pending.box.tx1 - pending.box.tx0 + 1) * (pending.box.ty1 - pending.box.ty0 + 1);
+  return false;
+}
+
+// Rare path: Sutherland-Hodgman against the six planes, then a fan from the first vertex.
+PBR_DEV void clip_one(const FrameParams* p, const VertexOut* vout, const uint32_t* indices, const BinTargets& bt, int inst, int t, int n_tris) {
+  VertexOut va, vb, vc;
+  fetch_triangle(p, vout, indices, bt, inst, t, va, vb, vc);
+  const uint32_t id = (uint32_t)inst * (uint32_t)n_tris + (uint32_t)t;
   float4 poly[12], tmp[12];
   int n = 3;
-  poly[0] = a; poly[1] = b; poly[2] = c;
+  poly[0] = va.clip; poly[1] = vb.clip; poly[2] = vc.clip;
   for (int pl = 0; pl < 6 && n >= 3; ++pl) {
     int m = 0;
     for (int k = 0; k < n; ++k) {
@@ -253,31 +393,25 @@ PBR_DEV void setup_one(const FrameParams* p, const VertexOut* vout, const uint32
     n = m;
     for (int k = 0; k < n; ++k) poly[k] = tmp[k];
   }
-  for (int k = 1; k + 1 < n; ++k) emit_triangle(id, poly[0], poly[k], poly[k + 1], p, bt, nullptr);
+  for (int k = 1; k + 1 < n; ++k) emit_piece(id, poly[0], poly[k], poly[k + 1], p, bt);
 }
 
 __global__ void __launch_bounds__(256) setup_kernel(const FrameParams frame_params, const VertexOut* __restrict__ vout,
                                                     const uint32_t* __restrict__ indices, BinTargets bt, int n_tris, int blocks_per_instance,
                                                     SkyShare share) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
-  if ((int)blockIdx.x >= share.own_blocks) { sky_tile(p, share.sky, share.rgba8, share.first + (int)blockIdx.x - share.own_blocks); return; }
+  SETUP_TRACE(0);
+  if ((int)blockIdx.x >= share.own_blocks) { sky_tile(p, share.sky, share.rgba8, share.first + (int)blockIdx.x - share.own_blocks); SETUP_TRACE(4); return; }
   const int inst = (int)blockIdx.x / blocks_per_instance;
   const int t = ((int)blockIdx.x - inst * blocks_per_instance) * 256 + threadIdx.x;
-  Deferred d;
-  d.slot = 0xffffffffu; d.box = 0;
-  if (t < n_tris) setup_one(p, vout, indices, bt, inst, t, n_tris, &d);
-  // wave-cooperative binning of the triangles that span many tiles: one tile per lane
-  unsigned long long todo = __ballot(d.slot != 0xffffffffu);
-  const int lane = threadIdx.x & 63;
-  while (todo) {
-    const int src = __ffsll((long long)todo) - 1;
-    todo &= todo - 1;
-    const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)d.slot, src);
-    const int box = __builtin_amdgcn_readlane(d.box, src);
-    const int tx0 = box & 255, tx1 = (box >> 8) & 255, ty0 = (box >> 16) & 255, ty1 = (box >> 24) & 255;
-    const int bw = tx1 - tx0 + 1, n = bw * (ty1 - ty0 + 1);
-    for (int i = lane; i < n; i += 64) bin_reference(p, bt, (uint32_t)((ty0 + i / bw) * p->tiles_x + tx0 + i % bw), slot);
-  }
+  __shared__ BinWindow s_window[4];
+  Pending pending;
+  pending.n_tiles = 0;
+  const bool crosses = t < n_tris && setup_one(p, vout, indices, bt, inst, t, n_tris, pending);
+  SETUP_TRACE(3);
+  bin_wave(p, bt, pending, threadIdx.x & 63, &s_window[threadIdx.x >> 6]);
+  if (crosses) clip_one(p, vout, indices, bt, inst, t, n_tris);
+  SETUP_TRACE(4);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -341,12 +475,21 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
   int tile, tile_x, tile_y;
   uint32_t n;
   bool clear_count = true;
+  uint32_t first_ref = 0u;
+  bool have_first_ref = false;
   if ((int)blockIdx.y < listed_rows) {
+    // Every memory round trip here is 1.5 - 2 us on the frame's critical path (the launch ends with the fullest of
+    // these tiles): one load says whether there is a k-th listed tile and which, and the tile's first references
+    // are fetched next to the atomic that returns how many of them count.
     const uint32_t k = blockIdx.y * gridDim.x + blockIdx.x;
-    if (k >= min(counters[4], live.cap)) return;
-    tile = (int)live.tiles[k];
+    if (k >= live.cap) return;
+    const unsigned long long listed = live.tiles[k];
+    if ((listed >> 24) != live.serial) return;
+    tile = (int)(listed & 0xffffffull);
     tile_y = p->tiles_x == 1 ? tile : (int)__umulhi((uint32_t)tile, p->tiles_x_magic); tile_x = tile - tile_y * p->tiles_x;
     if (tid == 0) s_base[0] = atomicOr(&tile_count[tile], kVisited);
+    first_ref = bins[(size_t)tile * PBR_BIN_CAP + (uint32_t)kRasterWaves * lane + wave];   // the entry of this lane in the first round below
+    have_first_ref = true;
     __syncthreads();
     n = s_base[0] & ~kVisited;
     clear_count = (s_base[0] & kVisited) != 0u;
@@ -386,7 +529,7 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
       uint32_t id = 0;
       const uint32_t entry = chunk + (uint32_t)kRasterWaves * lane + wave;
       uint32_t slot = 0xffffffffu;
-      if (entry < n_row) slot = bins[(size_t)tile * PBR_BIN_CAP + entry];
+      if (entry < n_row) slot = have_first_ref && chunk == 0u ? first_ref : bins[(size_t)tile * PBR_BIN_CAP + entry];
       else if (entry < n_entries) { const uint2 pr = overflow[entry - n_row]; if (pr.x == (uint32_t)tile) slot = pr.y; }
       if (slot != 0xffffffffu) {
         const SetupTri t = setup[slot];
@@ -556,8 +699,12 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
   if (tid == 0) {
     const uint32_t tu = (s_pairs[0] & 0xffffu) + (s_pairs[1] & 0xffffu) + (s_pairs[2] & 0xffffu) + (s_pairs[3] & 0xffffu);
     const uint32_t tm = (s_pairs[0] >> 16) + (s_pairs[1] >> 16) + (s_pairs[2] >> 16) + (s_pairs[3] >> 16);
-    s_base[0] = tu ? atomicAdd(&counters[6], tu) : 0u;
-    s_base[1] = tm ? atomicAdd(&counters[7], tm) : 0u;
+    // the two lists' counters are neighbours on an 8-byte boundary: one 64-bit atomic reserves room in both (two
+    // 32-bit ones are issued one after the other's answer, 2 us each at the end of every tile with geometry, the
+    // frame's fullest tile included)
+    unsigned long long at = 0ull;
+    if (tu | tm) at = atomicAdd(reinterpret_cast<unsigned long long*>(counters + 6), (unsigned long long)tu | ((unsigned long long)tm << 32));
+    s_base[0] = (uint32_t)at; s_base[1] = (uint32_t)(at >> 32);
   }
   __syncthreads();
   uint32_t at_u = s_base[0], at_m = s_base[1];
@@ -720,6 +867,9 @@ __global__ void __launch_bounds__(256) raster_msaa_kernel(const FrameParams fram
 }  // namespace
 
 #ifdef PBR_SURFACE_TRACE
+extern "C" int pbr_debug_setup_trace(unsigned long long* out, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_setup_trace), bytes < sizeof(g_setup_trace) ? bytes : sizeof(g_setup_trace));
+}
 extern "C" int pbr_debug_raster_trace(unsigned long long* out, size_t bytes) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_raster_trace), bytes < sizeof(g_raster_trace) ? bytes : sizeof(g_raster_trace));
 }
