@@ -61,7 +61,13 @@ def measured_traffic(kernel):
     itself runs without a profiler); None if there is none."""
     try:
         with open(TRAFFIC_FILE) as f:
-            return float(json.load(f)[kernel]["hbm_bytes"])
+            table = json.load(f)
+        if kernel in table:
+            return float(table[kernel]["hbm_bytes"])
+        # a templated kernel is listed once per instantiation ("name<256>", "name<1024>"): the one launched most often
+        # in the measured run is the one the timed region launches
+        shapes = [v for k, v in table.items() if k.startswith(kernel + "<")]
+        return float(max(shapes, key=lambda v: v["launches"])["hbm_bytes"]) if shapes else None
     except (OSError, KeyError, ValueError):
         return None
 

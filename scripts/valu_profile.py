@@ -26,7 +26,7 @@ def counters(path):
     out, cur = collections.defaultdict(dict), None
     for line in open(path):
         if not line.startswith(" "):
-            cur = next((k for k in KERNELS if k + "(" in line), None)
+            cur = next((k for k in KERNELS if k + "(" in line or k + "<" in line), None)   # "<": an instantiation of a templated kernel
             continue
         parts = line.split()
         if cur and len(parts) >= 2 and parts[0] in WANT:
@@ -40,14 +40,17 @@ def mix(kernel):
         lst = os.path.join(d, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-fast-math", "-fno-slp-vectorize", *extra, "-S",
                         "--cuda-device-only", "-o", lst, os.path.join(ROOT, "wgpu-renderer_amd", "csrc", src)], check=True, stderr=subprocess.DEVNULL)
-        c, name = collections.Counter(), None
+        c, name, first = collections.Counter(), None, None
         for raw in open(lst):
             m = re.match(r"^(_Z\w+):", raw)
             if m:
                 name = m.group(1)
+                # a templated kernel is compiled once per instantiation ("...kernelILi1024EE..."): the first is counted
+                if first is None and re.search(r"\d+" + kernel + "[EI]", name):
+                    first = name
                 continue
             text = raw.strip()
-            if name and re.search(r"\d+" + kernel + "E", name) and text.startswith("v_"):
+            if name is not None and name == first and text.startswith("v_"):
                 c[cost.classify(text)] += 1
     n = sum(c.values())
     return {"compiled_vector_instructions": dict(c), "issue_cycles_per_instruction": round(sum(cost.CYCLES[k] * v for k, v in c.items()) / n, 3)}
