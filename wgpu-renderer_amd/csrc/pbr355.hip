@@ -552,7 +552,8 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
                        counters, next_counters, c->d_tile_live, write_vis || c->capture_depth, tiles_x, tiles_y, fw.live);
   else
     launch_raster(s, dp, fw.setup, fw.tile_count, fw.bins, fw.overflow, (uint32_t)fw.overflow_cap, vis, (c->capture_depth && !static_memory) ? c->d_depth : nullptr,
-                  counters, next_counters, fw.lists, write_vis, apr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y, fw.live);
+                  counters, next_counters, fw.lists, write_vis, apr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y, fw.live,
+                  /*split_listed=*/c->parent == nullptr && c->children == 0);   // a context on its own: see the kernel
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
 
   ResolveInputs in;

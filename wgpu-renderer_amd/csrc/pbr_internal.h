@@ -202,7 +202,7 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSourc
                           const LiveTiles& live, int n_tris, int n_instances, const SkyShare& share);
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                    uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, const QuadLists& lists, bool write_vis,
-                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y, const LiveTiles& live);
+                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y, const LiveTiles& live, bool split_listed);
 struct ResolveInputs {
   const TriRecord* records;
   const VertexOut* vout;

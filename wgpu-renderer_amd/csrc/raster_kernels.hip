@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
                                                      const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
                                                      float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters,
                                                      QuadLists lists, int write_vis, DevCubeRgb sky, uint32_t* __restrict__ rgba8, int sky_from_tile,
-                                                     LiveTiles live, int listed_rows) {
+                                                     LiveTiles live, int listed_rows, int listed_parts) {
   const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
   __shared__ uint32_t s_pairs[kRasterWaves], s_base[2];
@@ -466,13 +466,18 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
   // leaves at once if the tile was taken from the list.  Only the full tiles go first: all tiles with geometry at the
   // head of every launch cost 4 us per frame with four frames in flight, whose rasterisers then hold the chip's
   // wave slots with latency-bound loops at the same time.
-  // A listed tile's reference count is read by two workgroups, the one that rasterises it and the tile's own, in either
-  // order, and has to be zero again for the next frame: each marks its visit in the count's top bit, and the one that
-  // finds the mark already there is the second and does the clearing.
-  constexpr uint32_t kVisited = 0x80000000u;
+  // With the chip to itself (listed_parts 2) a listed tile is rasterised by two workgroups, its upper and its lower
+  // sixteen rows: the time of a full tile is that of its per-triangle loop, one wavefront issuing an instruction every
+  // 7 - 8 cycles, and two workgroups halve the blocks each sweeps (not the triangles each sets up): rasteriser 36 -> 31 us,
+  // single 4K frame 82.4 -> 78.2 us.  With other frames in flight the doubled set-up work costs more than the shorter
+  // tail gains (53.3 against 52.7 us per frame), and one workgroup takes the whole tile (listed_parts 1).
+  // A listed tile's reference count is therefore read by listed_parts + 1 workgroups, the parts' and the tile's own, in
+  // any order, and has to be zero again for the next frame: each counts its visit in the count's top two bits, and the
+  // last does the clearing.
+  constexpr uint32_t kVisit = 1u << 30, kCountMask = kVisit - 1u;
   // (the listed tiles' workgroups are whole rows of the grid ahead of the tiles' own rows, so that a tile's own
   // workgroup finds its tile coordinates in its block index without a division)
-  int tile, tile_x, tile_y;
+  int tile, tile_x, tile_y, first_row = 0, rows = PBR_TILE;
   uint32_t n;
   bool clear_count = true;
   uint32_t first_ref = 0u;
@@ -481,38 +486,44 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
     // Every memory round trip here is 1.5 - 2 us on the frame's critical path (the launch ends with the fullest of
     // these tiles): one load says whether there is a k-th listed tile and which, and the tile's first references
     // are fetched next to the atomic that returns how many of them count.
-    const uint32_t k = blockIdx.y * gridDim.x + blockIdx.x;
-    if (k >= live.cap) return;
+    const uint32_t block = blockIdx.y * gridDim.x + blockIdx.x, parts = (uint32_t)listed_parts, k = parts == 2u ? block >> 1 : block;
+    if (k >= live.cap || parts * k + parts - 1u >= (uint32_t)listed_rows * gridDim.x) return;   // (a lone last workgroup has no partner: the tile's own takes it)
     const unsigned long long listed = live.tiles[k];
     if ((listed >> 24) != live.serial) return;
     tile = (int)(listed & 0xffffffull);
     tile_y = p->tiles_x == 1 ? tile : (int)__umulhi((uint32_t)tile, p->tiles_x_magic); tile_x = tile - tile_y * p->tiles_x;
-    if (tid == 0) s_base[0] = atomicOr(&tile_count[tile], kVisited);
+    rows = PBR_TILE / (int)parts; first_row = (int)(block & (parts - 1u)) * rows;
+    if (tid == 0) s_base[0] = atomicAdd(&tile_count[tile], kVisit);
     first_ref = bins[(size_t)tile * PBR_BIN_CAP + (uint32_t)kRasterWaves * lane + wave];   // the entry of this lane in the first round below
     have_first_ref = true;
     __syncthreads();
-    n = s_base[0] & ~kVisited;
-    clear_count = (s_base[0] & kVisited) != 0u;
+    n = s_base[0] & kCountMask;
+    clear_count = (s_base[0] >> 30) == parts;
     __syncthreads();   // s_base is used again below
   } else {
     tile_x = (int)blockIdx.x; tile_y = (int)blockIdx.y - listed_rows;
     tile = tile_y * p->tiles_x + tile_x;
-    n = tile_count[tile] & ~kVisited;
+    n = tile_count[tile] & kCountMask;
     if (n > PBR_DENSE_TILE_REFS) {
       const unsigned long long v = live.info[tile];
       const uint32_t k = (uint32_t)(v & 0xffffu) - 1u;   // position in the list
-      if ((v >> 16) == live.serial && k < (uint32_t)listed_rows * gridDim.x && k < live.cap) {
-        if (tid == 0 && (atomicOr(&tile_count[tile], kVisited) & kVisited) != 0u) tile_count[tile] = 0u;
+      const uint32_t parts = (uint32_t)listed_parts;
+      if ((v >> 16) == live.serial && parts * k + parts - 1u < (uint32_t)listed_rows * gridDim.x && k < live.cap) {
+        if (tid == 0 && (atomicAdd(&tile_count[tile], kVisit) >> 30) == parts) tile_count[tile] = 0u;
         return;
       }
     }
   }
-  const int px0 = tile_x * PBR_TILE, py0 = p->y0 + tile_y * PBR_TILE;   // tile origin in pixels
+  const int px0 = tile_x * PBR_TILE, py0 = p->y0 + tile_y * PBR_TILE + first_row;   // origin in pixels of the tile, or of the half
   RASTER_TRACE(0, wall_clock64()); RASTER_TRACE(3, (unsigned long long)n);
   // the first PBR_BIN_CAP references sit in the tile's own row; a fuller tile also filters the shared overflow list
   const uint32_t n_row = min(n, (uint32_t)PBR_BIN_CAP);
   const uint32_t n_entries = n_row + (n > PBR_BIN_CAP ? min(counters[1], overflow_cap) : 0u);
-  const int xmax = min(px0 + PBR_TILE, p->W) - 1, ymax = min(py0 + PBR_TILE, p->y1) - 1;
+  const int xmax = min(px0 + PBR_TILE, p->W) - 1, ymax = min(py0 + rows, p->y1) - 1;
+  if (py0 > ymax) {   // the lower half of a tile that the target's edge cuts above it
+    if (tid == 0 && clear_count) tile_count[tile] = 0u;
+    return;
+  }
   const unsigned long long clear_key = (unsigned long long)depth_key(1.0f) << 32;   // depth clear 1.0, no triangle
 
   if (n != 0u) {
@@ -901,11 +912,12 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSourc
 
 void launch_raster(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
                    uint32_t overflow_cap, uint32_t* vis, float* depth, uint32_t* counters, uint32_t* next_counters, const QuadLists& lists, bool write_vis,
-                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y, const LiveTiles& live) {
+                   const DevCubeRgb& sky_bordered, uint8_t* rgba8, int sky_from_tile, int tiles_x, int tiles_y, const LiveTiles& live, bool split_listed) {
   const int n_tiles = tiles_x * tiles_y, listed_blocks = std::min(n_tiles, (int)live.cap);
-  const int listed_rows = (listed_blocks + tiles_x - 1) / tiles_x;
+  const int listed_parts = split_listed ? 2 : 1;
+  const int listed_rows = (listed_parts * listed_blocks + tiles_x - 1) / tiles_x;
   hipLaunchKernelGGL(raster_kernel, dim3(tiles_x, listed_rows + tiles_y), dim3(kRasterThreads), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis,
-                     depth, counters, next_counters, lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile, live, listed_rows);
+                     depth, counters, next_counters, lists, write_vis ? 1 : 0, sky_bordered, reinterpret_cast<uint32_t*>(rgba8), sky_from_tile, live, listed_rows, listed_parts);
 }
 
 void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* setup, uint32_t* tile_count, const uint32_t* bins, const uint2* overflow,
