@@ -84,3 +84,34 @@ def write_large_two_primitive_mesh(directory, n=272):
     verts = np.concatenate([np.concatenate([pos, uv, nrm], 1), np.concatenate([qpos, quv, qnrm], 1)]).astype(np.float32)
     indices = np.concatenate([idx, qidx.astype(np.uint32) + np.uint32(nv)])
     return path, verts, indices
+
+
+def write_scattered_triangles(directory, n=6000, seed=7):
+    """n triangles facing +z, scattered over more than the default view in random order: most a few pixels across at
+    1280 x 720, one in 250 hundreds of pixels.  Neighbours in the index buffer are nowhere near each other on screen,
+    unlike those of a modelled mesh.  Returns the path."""
+    rng = np.random.default_rng(seed)
+    centre = np.stack([rng.uniform(-3.9, 3.9, n), rng.uniform(-2.2, 2.2, n), rng.uniform(-0.6, 0.6, n)], -1)
+    size = np.where(rng.random(n) < 0.004, rng.uniform(0.4, 1.2, n), rng.uniform(0.008, 0.06, n))
+    ang = rng.uniform(0.0, 2.0 * np.pi, n)[:, None] + np.float64([0.0, 2.1, 4.2]) + rng.uniform(-0.4, 0.4, (n, 3))   # increasing: counter-clockwise
+    corner = centre[:, None, :] + np.stack([np.cos(ang), np.sin(ang), np.zeros_like(ang)], -1) * size[:, None, None]
+    corner[:, :, 2] += rng.uniform(-0.05, 0.05, (n, 3))
+    pos = corner.reshape(-1, 3).astype(np.float32)
+    nrm = np.tile(np.float32([0, 0, 1]), (3 * n, 1))
+    uv = rng.random((3 * n, 2)).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32)
+    chunks = [pos.tobytes(), nrm.tobytes(), uv.tobytes(), idx.tobytes()]
+    offs = np.cumsum([0] + [len(ch) for ch in chunks])
+    views = [{"buffer": 0, "byteOffset": int(offs[k]), "byteLength": len(chunks[k])} for k in range(4)]
+    acc = [{"bufferView": 0, "componentType": 5126, "count": 3 * n, "type": "VEC3"}, {"bufferView": 1, "componentType": 5126, "count": 3 * n, "type": "VEC3"},
+           {"bufferView": 2, "componentType": 5126, "count": 3 * n, "type": "VEC2"}, {"bufferView": 3, "componentType": 5125, "count": 3 * n, "type": "SCALAR"}]
+    gltf = {"asset": {"version": "2.0"}, "buffers": [{"uri": "scatter.bin", "byteLength": int(offs[-1])}], "bufferViews": views, "accessors": acc,
+            "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.6, 0.3, 1.0]}, "emissiveFactor": [0.0, 0.0, 0.0]}],
+            "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0}]}],
+            "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}], "scene": 0}
+    with open(os.path.join(directory, "scatter.bin"), "wb") as f:
+        f.write(b"".join(chunks))
+    path = os.path.join(directory, "scatter.gltf")
+    with open(path, "w") as f:
+        json.dump(gltf, f)
+    return path

@@ -829,6 +829,24 @@ def test_general_gltf_scene_matches_oracle(tmp_path):
     assert_frame_close(rgba, orgba, vis, ovis, "interleaved quad")
 
 
+def test_scattered_triangles_match_oracle(tmp_path):
+    """Six thousand triangles in random order all over a 1280 x 720 target (40 x 23 tiles): the triangles of one
+    wavefront of the set-up launch are nowhere near each other, so their tiles do not fit the 16 x 16-tile window the
+    launch bins through and it takes its per-triangle path; one in 250 spans hundreds of pixels (the path of the
+    triangles over sixteen tiles), and some cross the target's edges.  Visibility bit for bit, both pipelines."""
+    import gltf_samples
+    path = gltf_samples.write_scattered_triangles(str(tmp_path))
+    scene = pu.SmallScene.build(width=1280, height=720, model_path=path, reference_limits=False)
+    for msaa in (False, True):
+        scene.renderer.msaa_options["enable"] = msaa
+        rgba, vis = scene.render_gpu()
+        orgba, ovis = scene.render_oracle()
+        assert (vis == ovis).all()
+        assert_frame_close(rgba, orgba, vis, ovis, f"scattered triangles msaa={msaa}")
+        assert len(np.unique(vis)) > 3000 and 0.1 < (vis > 0).mean() < 0.9
+    scene.renderer.close()
+
+
 def test_wide_index_mesh_matches_oracle(tmp_path):
     """A mesh of 73 988 vertices in two primitives: 32-bit indices from the loader through the C ABI to the
     kernels (pbr_upload_mesh_u32), against the oracle reading the same 32-bit indices."""
