@@ -523,13 +523,19 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // workgroups; the rasteriser shades the rest (each workgroup its own tile).
   const int n_tiles = tiles_x * tiles_y;
   // Skybox tiles that ride in the setup launch; the rasteriser's launch shades the rest.  With frames in flight a
-  // third is best (54.2 / 54.6 / 55.4 / 56.0 us per 4K frame at 0.35 / 0.45 / 0.55 / 0.65); one frame at a time does
-  // not care (88.6 - 90.0 us over the same range).  A measurement build sets another share with
-  // -DPBR_SKY_SHARE_SETUP=...; the library reads no environment variable.
+  // third is best (52.6 / 52.8 / 53.9 / 54.2 us per 4K frame at 0.35 / 0.45 / 0.55 / 0.65).  A context on its own
+  // wants more than half there: its rasteriser's launch lasts as long as its skybox tiles do, while the set-up launch
+  // waits on its triangles (single frame 78.1 / 76.8 / 76.0 / 76.4 us over the same range).  Measurement builds set
+  // other shares with -DPBR_SKY_SHARE_SETUP=... / -DPBR_SKY_SHARE_SETUP_ALONE=...; the library reads no environment
+  // variable.
 #ifndef PBR_SKY_SHARE_SETUP
 #define PBR_SKY_SHARE_SETUP 0.35f
 #endif
-  constexpr float share_setup = PBR_SKY_SHARE_SETUP;
+#ifndef PBR_SKY_SHARE_SETUP_ALONE
+#define PBR_SKY_SHARE_SETUP_ALONE 0.55f
+#endif
+  const bool alone = c->parent == nullptr && c->children == 0;   // no forks: nothing else of this scene is in flight
+  const float share_setup = alone ? PBR_SKY_SHARE_SETUP_ALONE : PBR_SKY_SHARE_SETUP;
   // A frame has no vertex launch: the setup kernel transforms each triangle's vertices from the streams itself
   // and leaves a shading record per triangle, which is all the resolve kernels read.
   // The multisampled resolve blends over the skybox colour, which therefore has to be complete before the
@@ -553,7 +559,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   else
     launch_raster(s, dp, fw.setup, fw.tile_count, fw.bins, fw.overflow, (uint32_t)fw.overflow_cap, vis, (c->capture_depth && !static_memory) ? c->d_depth : nullptr,
                   counters, next_counters, fw.lists, write_vis, apr->sky_b.cube, color, sky_from_tile, tiles_x, tiles_y, fw.live,
-                  /*split_listed=*/c->parent == nullptr && c->children == 0);   // a context on its own: see the kernel
+                  /*split_listed=*/alone);   // see the kernel
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[3], s));
 
   ResolveInputs in;
@@ -565,7 +571,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
   if (msaa) launch_surface_msaa(s, dp, in, pr->d_srgb_lut, vis, c->d_tile_live, color, W, rows, fast);
   // a context that shares its scene with forks is one of several frames in flight on this chip (see the two shapes of the surface kernel)
-  else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, fw.lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks, c->parent != nullptr || c->children > 0);
+  else launch_surface(s, dp, in, pr->d_srgb_lut, vis, color, fw.lists, counters, W, rows, tiles_x, tiles_y, fast, pr->surface_blocks, /*shared_chip=*/!alone);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[4], s));
   if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
