@@ -675,7 +675,7 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
       uint32_t c[4];
       sky_pixels4(p, sky, x, y, c);
       if (wide && !(ids[0] | ids[1] | ids[2] | ids[3])) {
-        *reinterpret_cast<uint4*>(rgba8 + o) = make_uint4(c[0], c[1], c[2], c[3]);
+        store_colour4(rgba8 + o, c);
       } else {
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (x + k <= xmax && !ids[k]) rgba8[o + k] = c[k];

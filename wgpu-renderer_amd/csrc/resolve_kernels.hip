@@ -811,7 +811,7 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   const P3 specular = pf * (kS * brdf.x + brdf.y);
   const P3 ambient = (kD * p3(irr) * albedo + specular) * occlusion;
   const P3 color = ambient + p3(Lo) + emissive;
-  if (cov) rgba8[o] = pack_color(v3(color.rg.x, color.rg.y, color.b));
+  if (cov) __builtin_nontemporal_store(pack_color(v3(color.rg.x, color.rg.y, color.b)), rgba8 + o);   // streamed past the L2s: see store_colour4
 }
 
 // Work list driven: the rasteriser leaves two lists of 2x2 pixel quads that hold geometry, and background
