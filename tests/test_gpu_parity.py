@@ -757,6 +757,48 @@ def test_forked_contexts_draw_the_parents_scene(small):
     assert (rgba == want).all() and (vis == want_vis).all()
 
 
+def test_modes_in_turn_leave_nothing_behind(small):
+    """One context through its modes in turn: alone (listed tiles in two halves, more of the skybox with the set-up
+    launch, large surface workgroups), multisampled, sharing its scene with a fork (the other shapes of all three), in
+    strips, and alone again.  The per-tile reference counts carry visit marks that the last visitor clears and the
+    counters are re-armed by the frame before: anything left behind by one mode would show in the next frame's bytes."""
+    r = small.renderer
+    r.camera = small.pkg.Camera()
+    r.camera.update_camera_rotation(-40.0, 15.0)
+    r.msaa_options["enable"] = False
+    want, want_vis = small.render_gpu()
+    r.msaa_options["enable"] = True
+    ms, ms_vis = small.render_gpu()
+    r.msaa_options["enable"] = False
+    for _ in range(2):
+        rgba, vis = small.render_gpu()
+        assert (rgba == want).all() and (vis == want_vis).all()
+    fork = r.fork()
+    try:
+        fork.camera = r.camera
+        assert (fork.draw_frame() == want).all()
+        rgba, vis = small.render_gpu()                       # the parent, now one of two contexts on the scene
+        assert (rgba == want).all() and (vis == want_vis).all()
+        r.msaa_options["enable"] = True
+        rgba, vis = small.render_gpu()
+        assert (rgba == ms).all() and (vis == ms_vis).all()
+        r.msaa_options["enable"] = False
+        fork.msaa_options["enable"] = True
+        assert (fork.draw_frame() == ms).all()
+        fork.msaa_options["enable"] = False
+        assert (fork.draw_frame() == want).all()
+    finally:
+        fork.close()
+    h = small.height
+    cuts = [0, 64, 160, h]                                  # multiples of 32 and the ragged rest
+    for y0, y1 in zip(cuts[:-1], cuts[1:]):
+        rgba, vis = small.render_gpu(y0=y0, y1=y1)
+        assert (rgba == want[y0:y1]).all() and (vis == want_vis[y0:y1]).all(), (y0, y1)
+    rgba, vis = small.render_gpu()
+    assert (rgba == want).all() and (vis == want_vis).all()
+    r.camera = small.pkg.Camera()
+
+
 def test_error_reporting(small):
     lib, r = small.pkg._lib, small.renderer
     u = small.uniforms()
