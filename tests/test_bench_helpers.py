@@ -20,6 +20,16 @@ def test_committed_traffic_measurement_is_readable():
     assert b.measured_traffic("no_such_kernel") is None
 
 
+def test_traffic_of_a_templated_kernel_is_that_of_its_most_launched_shape(tmp_path, monkeypatch):
+    import json
+    b = _bench()
+    path = tmp_path / "traffic.json"
+    path.write_text(json.dumps({"k<256>": {"launches": 70, "hbm_bytes": 5.0e7}, "k<1024>": {"launches": 3, "hbm_bytes": 4.0e7},
+                                "plain": {"launches": 1, "hbm_bytes": 1.0e6}}))
+    monkeypatch.setattr(b, "TRAFFIC_FILE", str(path))
+    assert b.measured_traffic("k") == 5.0e7 and b.measured_traffic("plain") == 1.0e6 and b.measured_traffic("kk") is None
+
+
 def test_committed_instruction_counts_are_readable():
     b = _bench()
     one = b.valu_issue(["resolve_surface_fast_kernel"], 0.037)
