@@ -109,8 +109,10 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=None)
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--skybox-size", type=int, default=1024)
-    ap.add_argument("--in-flight", type=int, default=4,
+    ap.add_argument("--in-flight", type=int, default=3,
                     help="frames in flight per GPU: one renderer context plus forks of it, each on its own stream, take the rank's frames in turn")
+    ap.add_argument("--views", type=int, default=4,
+                    help="frames per pass: each context draws this many consecutive frames of the orbit with one pbr_draw_views_device call (1..4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the IBL prefilter timing (2048^2, 10 mips)")
     ap.add_argument("--prefilter-size", type=int, default=2048)
@@ -249,13 +251,14 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
     world, rank, local_rank, use_dist, dev, frame_streams = ctxinfo
     W, H = args.width, args.height
     K = max(1, args.in_flight)
+    V = min(4, max(1, args.views))
     r = pkg.Renderer(width=W, height=H, device=local_rank, skybox_size=args.skybox_size)
     r.init()
-    lanes = []                                # one context (the first owns the scene, the others are forks of it) + stream + colour target per frame in flight
+    lanes = []                                # one context (the first owns the scene, the others are forks of it) + stream + colour targets (one per view of a pass) per pass in flight
     for k in range(K):
         rr = r if k == 0 else r.fork()
         rr.set_stream(frame_streams[k].cuda_stream)   # a real (non-null) stream, so torch events and syncs see the kernels
-        lanes.append((rr, frame_streams[k], torch.empty((H, W, 4), dtype=torch.uint8, device=dev)))
+        lanes.append((rr, frame_streams[k], [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(V)]))
     lib = r._lib
     torch.cuda.set_stream(lanes[0][1])
 
@@ -271,17 +274,31 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
         for _ in range(world):
             r.camera.update_camera_rotation(-10.0, 0.0)
 
-    def step(i):
-        rr, _, color = lanes[i % K]
-        rr.draw_frame_device(color.data_ptr(), uniforms=uniforms[i])
+    def draw(rr, colors, lo, hi):
+        """frames [lo, hi) of this rank on one context: one frame, or one pass of several views"""
+        if hi - lo == 1:
+            rr.draw_frame_device(colors[0].data_ptr(), uniforms=uniforms[lo])
+        else:
+            rr.draw_views_device(uniforms[lo:hi], [colors[v].data_ptr() for v in range(hi - lo)])
 
+    def make_step(first, count):
+        """step i of `count` steps that start at frame `first`: with V frames per pass, every V-th step submits the pass
+        of its V frames (the last pass may be shorter), the steps between submit nothing"""
+        def step(i):
+            if i % V == 0:
+                rr, _, colors = lanes[(i // V) % K]
+                draw(rr, colors, first + i, first + min(i + V, count))
+        return step
+
+    warm = make_step(0, args.warmup)
     for i in range(args.warmup):
-        step(i)
+        warm(i)
     torch.cuda.synchronize(dev)
     # the dominant kernel inside the timed region: timed on the first context's stream, on the first quarter (at least
-    # eight) of the frames that context renders: an event pair costs about 10 us of stream time
-    pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, max(8, (args.steps + K - 1) // K // 4)))
-    elapsed = timed_region(torch, dist, use_dist, dev, args.steps, lambda i: step(args.warmup + i))
+    # eight) of the passes that context renders: an event pair costs about 10 us of stream time
+    n_passes = (args.steps + V - 1) // V
+    pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, max(8, (n_passes + K - 1) // K // 4)))
+    elapsed = timed_region(torch, dist, use_dist, dev, args.steps, make_step(args.warmup, args.steps))
     frames, surf_total, span = C.c_int32(), C.c_float(), C.c_float()
     pkg._lib.check(r._ctx, lib.pbr_profile_end(r._ctx, C.byref(frames), C.byref(surf_total), C.byref(span)))
     check_lanes(lanes)
@@ -289,29 +306,30 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
     # the dominant kernel with the chip to itself: same frames, first context only, one at a time.  The library launches
     # the surface kernel in one of two shapes, by whether the context shares its scene with forks (several frames in
     # flight) or not; while the forks exist this is the shape that ran in the timed region.
-    def isolated(n):
+    def isolated(n, views):
+        """n frames on the first context alone, `views` per pass; the profile counts launches of the surface kernel"""
         frames_, total_, span_ = C.c_int32(), C.c_float(), C.c_float()
         pkg._lib.check(r._ctx, lib.pbr_profile_begin(r._ctx, n))
-        for i in range(args.warmup, args.warmup + n):
-            r.draw_frame_device(lanes[0][2].data_ptr(), uniforms=uniforms[i])
+        for lo in range(args.warmup, args.warmup + n, views):
+            draw(r, lanes[0][2], lo, min(lo + views, args.warmup + n))
         pkg._lib.check(r._ctx, lib.pbr_profile_end(r._ctx, C.byref(frames_), C.byref(total_), C.byref(span_)))
         r.synchronize()
         return frames_, total_, span_
 
-    n_iso = min(args.steps, 20)
-    iso_frames, iso_total, iso_span = isolated(n_iso)
+    n_iso = max(V, min(args.steps, 20) // V * V)   # whole passes
+    iso_frames, iso_total, iso_span = isolated(n_iso, V)
     # the frame with nothing else in flight and no other context on the scene (config 2's "single frame"): the forks go first
     for rr, _, _ in lanes[1:]:
         rr.close()
     lanes = lanes[:1]
-    lone_frames, lone_total, lone_span = isolated(n_iso)
+    lone_frames, lone_total, lone_span = isolated(min(args.steps, 20), 1)
 
     # coverage for the bandwidth model: sampled on a second pass over a tenth of the timed views (a
     # statistics call synchronises, so it stays out of the timed region)
     stats = pkg._lib.FrameStats()
     cov_sum, tri_sum, n_cov = 0.0, 0, 0
     for i in range(args.warmup, args.warmup + args.steps, max(1, args.steps // 10)):
-        r.draw_frame_device(lanes[0][2].data_ptr(), uniforms=uniforms[i], stats=stats)
+        r.draw_frame_device(lanes[0][2][0].data_ptr(), uniforms=uniforms[i], stats=stats)
         cov_sum += stats.covered_pixels / float(W * H)
         tri_sum += stats.setup_triangles
         n_cov += 1
@@ -328,7 +346,8 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
         # write + one unique rgba8 texel from each of the 5 material textures.  Whole frame: vertex
         # and index streams once, visibility write + read and colour write per pixel, the 20 B of
         # texels per covered pixel and one rgba32f skybox texel per background pixel.
-        surf_bytes = c * npix * 28.0
+        surf_bytes_frame = c * npix * 28.0
+        surf_bytes = V * surf_bytes_frame           # one launch of the surface kernel shades the V views of a pass
         frame_bytes = n_verts * 32 + n_idx * 2 + npix * 12.0 + c * npix * 20.0 + (1.0 - c) * npix * 16.0
         in_flight_gbs = surf_bytes / (surf_ms * 1e-3) / 1e9
         iso_ms = iso_total.value / max(iso_frames.value, 1)
@@ -337,7 +356,8 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
         lone_ms = lone_total.value / max(lone_frames.value, 1)
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
         frame_traffic = measured_frame_traffic()
-        issue_one = valu_issue(["resolve_surface_fast_kernel"], iso_ms)
+        surf_traffic = measured_traffic("resolve_surface_fast_kernel")
+        issue_one = valu_issue(["resolve_surface_fast_kernel"], iso_ms / V)   # the committed counts are per frame
         issue_frame = valu_issue(FRAME_KERNELS, frame_ms)
         result = {
             "metric": "shaded Mpix/s (DamagedHelmet 4K PBR+IBL)",
@@ -355,18 +375,18 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
             "config": {"workload": f"DamagedHelmet {W}x{H} single frame, {args.skybox_size}^2 skybox cube, irradiance 32^2, prefilter 128^2 x5, LUT 512^2, synthetic 4096x2048 HDR"
                                    + f"; step i renders frame i of a 1-degree-per-frame camera orbit that starts at the reference's default view, frame f on rank f mod {world}",
                        "covered_fraction": c, "triangles": tri_sum // max(n_cov, 1), "parallelism": "replicas only" if world == 1 else f"frame-sharded x{world}",
-                       "frames_in_flight_per_gpu": K, "single_frame_ms": single_frame_ms,
+                       "frames_in_flight_per_gpu": K * V, "passes_in_flight_per_gpu": K, "views_per_pass": V, "single_frame_ms": single_frame_ms,
                        "single_frame_mpix_per_s": npix / 1e6 / (single_frame_ms * 1e-3),
-                       "covered_mpix_per_s_of_surface_kernel": c * npix / 1e6 / (iso_ms * 1e-3)},
+                       "covered_mpix_per_s_of_surface_kernel": V * c * npix / 1e6 / (iso_ms * 1e-3)},
             "kernel_ms": {"resolve_surface_fast_kernel": iso_ms, "resolve_surface_fast_kernel_in_flight": surf_ms, "resolve_surface_fast_kernel_lone_context": lone_ms,
                           "one_context_frame_to_frame": span.value / max(nf - 1, 1)},
             # the launch duration is the kernel's alone (nothing else on the chip); inside the timed region the same
             # kernel shares the chip with the other frames' kernels and its event-to-event time is longer than a step
             "roofline": {"bound": "hbm", "kernel": "resolve_surface_fast_kernel", "launch_ms": iso_ms, "achieved": iso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": iso_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("resolve_surface_fast_kernel"), "algorithmic_bytes": surf_bytes,
+                         "frac": iso_gbs / HBM_PEAK_GBS, "traffic": None if surf_traffic is None else V * surf_traffic, "algorithmic_bytes": surf_bytes, "views_per_launch": V,
                          "bound_measured": "latency of dependent load rounds at four waves per SIMD; busiest unit: vector issue", "valu_issue": issue_one,
-                         "lone_context": {"launch_ms": lone_ms, "achieved": surf_bytes / (lone_ms * 1e-3) / 1e9, "frac": surf_bytes / (lone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                          "note": "the kernel's other shape (one 1024-thread workgroup per compute unit), which the library launches for a context without forks"},
+                         "lone_context": {"launch_ms": lone_ms, "achieved": surf_bytes_frame / (lone_ms * 1e-3) / 1e9, "frac": surf_bytes_frame / (lone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "note": "one frame per launch, in the kernel's other shape (one 1024-thread workgroup per compute unit), which the library launches for a context without forks"},
                          "in_flight": {"ms": surf_ms, "achieved": in_flight_gbs, "frac": in_flight_gbs / HBM_PEAK_GBS,
                                        "note": "event-to-event time of the kernel inside the timed region, stretched by the other frames in flight"}},
             "frame_roofline": {"bound": "hbm", "kernels": "all kernels of one frame (setup + sky, raster + sky, surface); wall time per frame with the configured frames in flight",

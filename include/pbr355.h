@@ -176,6 +176,17 @@ int pbr_draw_frame(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w, int32_
  * next pbr_synchronize (PBR_E_STATE, "draw it again"). */
 int pbr_draw_frame_device(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1,
                           void* d_rgba8, void* d_vis, PbrFrameStats* stats);
+/* Several frames of one scene in one pass: view v is drawn with u[v] into d_rgba8[v] (n_views of each, 1 to 4; all
+ * views share the target size and row range), and every target ends up with exactly the bytes pbr_draw_frame_device
+ * would have given it.  For camera paths and other callers that have several frames' uniforms at hand (the reference
+ * draws one frame per requestAnimationFrame, renderer.ts:1820-1826, :2050, and submits it on its own, :2033): each of
+ * the pass's three launches then covers all the views, so their fixed costs are paid once per pass instead of once
+ * per frame.  Queues the pass and returns; overflow reporting as for pbr_draw_frame_device without stats.  Views with
+ * another sampler than the reference's default (index 15), multisampled views, or textures of differing sizes are
+ * drawn one after the other instead.  The context keeps working buffers per view (some 70 MB per further view at
+ * 3840 x 2160) until it is destroyed. */
+int pbr_draw_views_device(PbrContext* ctx, int32_t n_views, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1,
+                          void* const* d_rgba8);
 /* pbr_draw_frame_device for callers that cannot allocate device memory: code under HIP graph capture, serving
  * loops that must not touch the allocator, harnesses that forbid hipMalloc.  It has no counterpart in the
  * reference.  Same pass, same result bits, but everything the frame keeps between its launches (append counters,

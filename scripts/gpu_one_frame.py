@@ -1,5 +1,5 @@
-"""Renders a few 4K frames (for profilers) and prints the per-stage event times of the last ones:
-python scripts/gpu_one_frame.py [distance] [frames]"""
+"""Renders a few frames (4K unless a size is given) (for profilers) and prints the per-stage event times of the last ones:
+python scripts/gpu_one_frame.py [distance] [frames] [width] [height]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,7 +7,9 @@ import __graft_entry__ as entry
 pkg = entry.load_package()
 dist = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-r = pkg.Renderer(width=3840, height=2160, skybox_size=1024)
+width = int(sys.argv[3]) if len(sys.argv) > 3 else 3840
+height = int(sys.argv[4]) if len(sys.argv) > 4 else 2160
+r = pkg.Renderer(width=width, height=height, skybox_size=1024)
 r.init()
 r.camera.update_camera_distance((5.0 - dist) * 100.0, 0.0)
 acc = {}

@@ -77,7 +77,8 @@ def test_gpus_flag_without_a_launcher_does_not_report_one_gpu(tmp_path):
 def test_modes_and_their_defaults():
     b = _bench()
     a = b.parse_args([])
-    assert (a.mode, a.width, a.height, a.steps, a.warmup, a.in_flight) == ("orbit", 3840, 2160, 360, 20, 4)
+    assert (a.mode, a.width, a.height, a.steps, a.warmup, a.in_flight, a.views) == ("orbit", 3840, 2160, 360, 20, 3, 4)
+    assert (a.steps % a.views, a.warmup % a.views) == (0, 0)   # whole passes in the timed region and before it
     s = b.parse_args(["--mode", "strips"])
     assert (s.width, s.height, s.steps) == (7680, 4320, 20)
 
@@ -87,7 +88,7 @@ def test_result_names_what_was_measured():
     nominal bytes from the measured traffic, and the single-frame latency from the pipelined rate."""
     text = open(os.path.join(ROOT, "bench.py")).read()
     for key in ('"single_frame_ms"', '"bound_measured"', '"launch_ms"', '"in_flight"', '"traffic_frac"', '"executed_samples"', '"reference_samples"',
-                '"cpu_baseline"', '"roofline"', '"frame_roofline"'):
+                '"cpu_baseline"', '"roofline"', '"frame_roofline"', '"views_per_pass"', '"views_per_launch"'):
         assert key in text, key
     assert "check_lanes(lanes)" in text          # every context is synchronised through the library after the timed region
     b = _bench()

@@ -560,6 +560,7 @@ def test_working_buffer_overflow_is_noticed_and_repaired():
         # the queued path: the incomplete frame is reported by the next synchronize, the one after it is whole
         lib.check(r._ctx, r._lib.pbr_debug_set_capacity(r._ctx, 1500, 64))
         out = torch.zeros((270, 480, 4), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the frames on the library's
         r.draw_frame_device(out.data_ptr())
         with pytest.raises(lib.PbrError, match="draw it again"):
             r.synchronize()
@@ -718,6 +719,7 @@ def test_forked_contexts_draw_the_parents_scene(small):
     try:
         streams = [torch.cuda.Stream() for _ in forks]
         outs = [torch.zeros((small.height, small.width, 4), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the frames on the library's
         for f, st in zip(forks, streams):
             f.set_stream(st.cuda_stream)
         views = []

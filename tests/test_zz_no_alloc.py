@@ -18,6 +18,7 @@ def _draw(scene, entry, width, height, y0=0, y1=None):
     y1 = height if y1 is None else y1
     u = r.frame_uniforms()
     out = torch.full((y1 - y0, width, 4), 0x5a, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()   # the fill runs on torch's stream, the frame on the library's
     rc = entry(r._ctx, C.byref(u), width, height, y0, y1, C.c_void_p(out.data_ptr()))
     scene.pkg._lib.check(r._ctx, rc)
     r.synchronize()
@@ -34,6 +35,7 @@ def test_static_frame_equals_device_frame():
         u = r.frame_uniforms()
         import torch
         probe = torch.zeros((360, 640, 4), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the frames on the library's
         # before any ordinary frame the lookup copies of the IBL maps do not exist, and this entry point may not build them
         assert static_entry(r._ctx, C.byref(u), 640, 360, 0, 360, C.c_void_p(probe.data_ptr())) == lib.PBR_E_STATE
         assert b"pbr_draw_frame_device" in r._lib.pbr_last_error(r._ctx)
@@ -56,6 +58,7 @@ def test_static_frame_equals_device_frame():
 
         # limits: 4K is 8160 tiles; the multisampled pipeline is not offered
         big = torch.zeros((2160, 3840, 4), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the frames on the library's
         r.width, r.height = 3840, 2160
         u = r.frame_uniforms()
         assert static_entry(r._ctx, C.byref(u), 3840, 2160, 0, 2160, C.c_void_p(big.data_ptr())) == lib.PBR_E_ARG
@@ -64,6 +67,7 @@ def test_static_frame_equals_device_frame():
         assert static_entry(r._ctx, C.byref(u), 3840, 2160, 1024, 1504, C.c_void_p(big.data_ptr())) == lib.PBR_OK
         r.synchronize()
         ref = torch.zeros((480, 3840, 4), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the frames on the library's
         lib.check(r._ctx, r._lib.pbr_draw_frame_device(r._ctx, C.byref(u), 3840, 2160, 1024, 1504, C.c_void_p(ref.data_ptr()), None, None))
         r.synchronize()
         assert torch.equal(big[:480], ref)
@@ -85,6 +89,7 @@ def test_static_frame_rejects_meshes_beyond_its_capacity():
     try:
         import torch
         out = torch.zeros((180, 320, 4), dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()   # the fill runs on torch's stream, the frames on the library's
         u = r.frame_uniforms()
         lib.check(r._ctx, r._lib.pbr_draw_frame_device(r._ctx, C.byref(u), 320, 180, 0, 180, C.c_void_p(out.data_ptr()), None, None))
         assert r._lib.pbr_draw_frame_static(r._ctx, C.byref(u), 320, 180, 0, 180, C.c_void_p(out.data_ptr())) == lib.PBR_E_ARG

@@ -242,7 +242,9 @@ void sky_affine(const float* m, int W, int H, FrameParams& fp) {
 // the context that owns the scene (mesh, textures, IBL maps): the context itself, or the one it was forked from
 PbrContext* assets_of(PbrContext* c) { return c->parent ? c->parent : c; }
 
-int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int samples) {
+// outputs: also the context's own colour target and visibility / depth buffers (a view slot has none: its view's
+// colours go to the caller's target and nothing else is written)
+int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int samples, bool outputs = true) {
   const size_t ntri = (size_t)(assets_of(c)->n_indices / 3) * assets_of(c)->n_instances;
   bool grew = false;
   if (ntri > c->record_cap) {
@@ -289,7 +291,7 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int sample
     HIP_TRY(c, hipMemset(c->d_live_info, 0, sizeof(unsigned long long) * n_tiles));   // serial 0: no frame
     c->tile_cap = n_tiles; grew = true;
   }
-  const size_t npix = (size_t)W * rows;
+  const size_t npix = outputs ? (size_t)W * rows : 0;
   if (npix > c->pix_cap) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_dev(c->d_color);
@@ -326,6 +328,9 @@ struct PbrContextPrivate {
   int surface_blocks = 0;                 // resident workgroups of the surface kernel on this device
   int counter_set = 0;                    // which of the two sets of append counters the next frame uses
   bool used_static = false;               // pbr_draw_frame_static has run: its overflow flag lives in the device's fixed array
+  // pbr_draw_views_device: hidden contexts that lend their working buffers and counters to views 1, 2, ... of a pass
+  // (view 0 works in the context's own)
+  std::vector<PbrContext*> view_slots;
 };
 static PbrContextPrivate* priv_of(PbrContext* c);
 
@@ -373,6 +378,41 @@ static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const
   return PBR_OK;
 }
 
+// The lookup copies derived from the IBL maps and material textures (bordered cubes, BRDF footprint table, interleaved
+// textures) belong to the scene's owner and are rebuilt on its stream; a forked context that finds them stale waits for
+// that stream before its own launches read them.
+static int refresh_lookup_copies(PbrContext* c, PbrContext* a, PbrContextPrivate* apr, bool one_size) {
+  int rc = PBR_OK;
+  if ((rc = refresh_bordered(a, apr->sky_b, a->sky)) || (rc = refresh_bordered(a, apr->irr_b, a->irr)) || (rc = refresh_bordered(a, apr->pre_b, a->pre))) return rc;
+  if (apr->lut_quad_dirty || apr->lut_quad_size != a->lut_size) {
+    if (apr->lut_quad_size != a->lut_size) {
+      HIP_TRY(c, hipStreamSynchronize(a->stream));
+      if (apr->d_lut_quad) { (void)hipFree(apr->d_lut_quad); apr->d_lut_quad = nullptr; }
+      HIP_TRY(c, hipMalloc(&apr->d_lut_quad, (size_t)a->lut_size * a->lut_size * sizeof(uint4)));
+      apr->lut_quad_size = a->lut_size;
+    }
+    launch_lut_quad(a->stream, a->d_lut, apr->d_lut_quad, a->lut_size);
+    apr->lut_quad_dirty = false;
+  }
+  if (one_size && (apr->atlas_dirty || !apr->d_atlas)) {
+    size_t texels;
+    uint32_t off[PBR_MAX_LEVELS];
+    tex8_offsets(a->tex[0].w, a->tex[0].h, a->tex[0].levels, off, &texels);
+    if (apr->atlas_texels != texels || !apr->d_atlas) {
+      HIP_TRY(c, hipStreamSynchronize(a->stream));
+      if (apr->d_atlas) { (void)hipFree(apr->d_atlas); apr->d_atlas = nullptr; }
+      HIP_TRY(c, hipMalloc(&apr->d_atlas, texels * sizeof(uint4)));
+      apr->atlas_texels = texels;
+    }
+    const uint32_t* chains[5];
+    for (int i = 0; i < 5; ++i) chains[i] = a->tex[i].base;
+    launch_material_atlas(a->stream, chains, apr->d_atlas, texels);
+    apr->atlas_dirty = false;
+  }
+  if (a != c) HIP_TRY(c, hipStreamSynchronize(a->stream));
+  return PBR_OK;
+}
+
 // The memory a frame works in between its launches: the context's own buffers (grown on demand) or, for
 // pbr_draw_frame_static, slices of the device's fixed scratch array.
 struct FrameWork {
@@ -385,6 +425,12 @@ struct FrameWork {
   uint32_t* counters; uint32_t* next_counters;
 };
 
+#ifndef PBR_SKY_SHARE_SETUP
+#define PBR_SKY_SHARE_SETUP 0.35f
+#endif
+#ifndef PBR_SKY_SHARE_SETUP_ALONE
+#define PBR_SKY_SHARE_SETUP_ALONE 0.55f
+#endif
 static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, int y0, int y1, void* d_rgba8, void* d_vis, bool want_host_vis,
                        PbrFrameStats* stats, bool static_memory = false) {
   PbrContext* a = assets_of(c);              // scene data may belong to the context this one was forked from
@@ -475,37 +521,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   const FrameParams& dp = fp;
   hipStream_t s = c->stream;
 
-  // The lookup copies derived from the IBL maps belong to the scene's owner and are rebuilt on its stream; a forked
-  // context that finds them stale waits for that stream before its own launches read them.
-  if (!static_memory && stale) {
-    if ((rc = refresh_bordered(a, apr->sky_b, a->sky)) || (rc = refresh_bordered(a, apr->irr_b, a->irr)) || (rc = refresh_bordered(a, apr->pre_b, a->pre))) return rc;
-    if (apr->lut_quad_dirty || apr->lut_quad_size != a->lut_size) {
-      if (apr->lut_quad_size != a->lut_size) {
-        HIP_TRY(c, hipStreamSynchronize(a->stream));
-        if (apr->d_lut_quad) { (void)hipFree(apr->d_lut_quad); apr->d_lut_quad = nullptr; }
-        HIP_TRY(c, hipMalloc(&apr->d_lut_quad, (size_t)a->lut_size * a->lut_size * sizeof(uint4)));
-        apr->lut_quad_size = a->lut_size;
-      }
-      launch_lut_quad(a->stream, a->d_lut, apr->d_lut_quad, a->lut_size);
-      apr->lut_quad_dirty = false;
-    }
-    if (one_size && (apr->atlas_dirty || !apr->d_atlas)) {
-      size_t texels;
-      uint32_t off[PBR_MAX_LEVELS];
-      tex8_offsets(a->tex[0].w, a->tex[0].h, a->tex[0].levels, off, &texels);
-      if (apr->atlas_texels != texels || !apr->d_atlas) {
-        HIP_TRY(c, hipStreamSynchronize(a->stream));
-        if (apr->d_atlas) { (void)hipFree(apr->d_atlas); apr->d_atlas = nullptr; }
-        HIP_TRY(c, hipMalloc(&apr->d_atlas, texels * sizeof(uint4)));
-        apr->atlas_texels = texels;
-      }
-      const uint32_t* chains[5];
-      for (int i = 0; i < 5; ++i) chains[i] = a->tex[i].base;
-      launch_material_atlas(a->stream, chains, apr->d_atlas, texels);
-      apr->atlas_dirty = false;
-    }
-    if (a != c) HIP_TRY(c, hipStreamSynchronize(a->stream));
-  }
+  if (!static_memory && stale && (rc = refresh_lookup_copies(c, a, apr, one_size))) return rc;
 
   const bool timed = stats != nullptr;
   const bool prof = c->profiling && c->prof_frames < c->prof_cap;
@@ -528,12 +544,6 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   // waits on its triangles (single frame 78.1 / 76.8 / 76.0 / 76.4 us over the same range).  Measurement builds set
   // other shares with -DPBR_SKY_SHARE_SETUP=... / -DPBR_SKY_SHARE_SETUP_ALONE=...; the library reads no environment
   // variable.
-#ifndef PBR_SKY_SHARE_SETUP
-#define PBR_SKY_SHARE_SETUP 0.35f
-#endif
-#ifndef PBR_SKY_SHARE_SETUP_ALONE
-#define PBR_SKY_SHARE_SETUP_ALONE 0.55f
-#endif
   const bool alone = c->parent == nullptr && c->children == 0;   // no forks: nothing else of this scene is in flight
   const float share_setup = alone ? PBR_SKY_SHARE_SETUP_ALONE : PBR_SKY_SHARE_SETUP;
   // A frame has no vertex launch: the setup kernel transforms each triangle's vertices from the streams itself
@@ -682,10 +692,12 @@ int pbr_fork(PbrContext* parent, PbrContext** ctx_out) {
 int pbr_destroy(PbrContext* c) {
   if (!c) return PBR_OK;
   if (c->children > 0) return fail(c, PBR_E_STATE, "%d forked context(s) still draw from this one: destroy them first", c->children);
-  if (c->parent) { --c->parent->children; c->parent = nullptr; }
+  if (c->parent) { if (!c->view_slot) --c->parent->children; c->parent = nullptr; }
   DeviceGuard guard(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   PbrContextPrivate* pr = priv_of(c);
+  for (PbrContext* slot : pr->view_slots) { slot->stream = slot->own_stream; (void)pbr_destroy(slot); }
+  pr->view_slots.clear();
   free_dev(c->d_vsoa); free_dev(c->d_indices); free_dev(c->d_inst_model); free_dev(c->d_inst_normal);
   for (auto& t : c->d_tex) free_dev(t);
   free_dev(c->d_hdr); free_dev(c->d_hdr_rgb); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
@@ -721,6 +733,10 @@ int pbr_synchronize(PbrContext* c) {
     uint32_t flag = 0;   // the capacity flag of the last pbr_draw_frame_static on this device
     HIP_TRY(c, hipMemcpy(&flag, g_scratch_ptr[c->device] + static_layout::kCounters + 2 * sizeof(uint32_t), sizeof flag, hipMemcpyDeviceToHost));
     if (flag) return fail(c, PBR_E_STATE, flag == 1 ? "triangle setup buffer overflow" : "tile bin overflow list full");
+  }
+  for (PbrContext* slot : priv_of(c)->view_slots) {   // views 1, 2, ... of the multi-view passes count in their slots' counters
+    HIP_TRY(c, hipMemcpy(slot->h_counters, slot->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (check_sticky(slot)) return fail(c, PBR_E_STATE, "%s", slot->error.c_str());
   }
   return check_sticky(c);
 }
@@ -1087,6 +1103,122 @@ int pbr_draw_frame_device(PbrContext* c, const PbrFrameUniforms* u, int32_t w, i
     if (!(rc == PBR_E_STATE && c->enlarged_after_overflow)) break;
   }
   return rc;
+}
+
+// A hidden context for one more view of a multi-view pass: working buffers and counters of its own, the scene of the
+// caller (not counted among the owner's forks: it is destroyed with the context that made it).
+static int make_view_slot(PbrContext* c, PbrContext** out) {
+  PbrContext* slot = nullptr;
+  const int rc = pbr_create(c->device, &slot);
+  if (rc) return fail(c, rc, "%s", pbr_last_error(nullptr));
+  slot->parent = assets_of(c);
+  slot->view_slot = true;
+  *out = slot;
+  return PBR_OK;
+}
+
+int pbr_draw_views_device(PbrContext* c, int32_t n_views, const PbrFrameUniforms* u, int32_t W, int32_t H, int32_t y0, int32_t y1, void* const* d_rgba8) {
+  if (!c) return PBR_E_ARG;
+  if (n_views < 1 || n_views > PBR_MAX_VIEWS) return fail(c, PBR_E_ARG, "%d views: a pass draws 1 to %d", n_views, PBR_MAX_VIEWS);
+  if (!u || !d_rgba8) return fail(c, PBR_E_ARG, "uniforms or colour output array is null");
+  for (int v = 0; v < n_views; ++v) {
+    if (!d_rgba8[v]) return fail(c, PBR_E_ARG, "colour output pointer of view %d is null", v);
+    for (int w = 0; w < v; ++w) if (d_rgba8[w] == d_rgba8[v]) return fail(c, PBR_E_ARG, "views %d and %d share one colour target", w, v);
+  }
+  PbrContext* a = assets_of(c);
+  PbrContextPrivate* apr = priv_of(a);
+  PbrContextPrivate* pr = priv_of(c);
+  // the one-launch pass exists for the specialised pipeline (the reference's default sampler on five power-of-two
+  // textures of one size, single-sampled); anything else is drawn view after view, with the same result
+  static const int kFormatSrgb[5] = {1, 0, 0, 1, 0};   // renderer.ts:647, :663, :681, :697, :713
+  bool one_size = a->d_tex[0] != nullptr;
+  for (int i = 0; i < 5 && one_size; ++i)
+    one_size = a->d_tex[i] && a->tex[i].base && a->tex[i].srgb == kFormatSrgb[i] && (a->tex[i].w & (a->tex[i].w - 1)) == 0 && (a->tex[i].h & (a->tex[i].h - 1)) == 0 &&
+               a->tex[i].w == a->tex[0].w && a->tex[i].h == a->tex[0].h && a->tex[i].levels == a->tex[0].levels;
+  bool fast = one_size && n_views > 1;
+  for (int v = 0; v < n_views; ++v) fast = fast && u[v].sampler_index == 15u;
+  if (!fast) {
+    for (int v = 0; v < n_views; ++v) {
+      const int rc = pbr_draw_frame_device(c, &u[v], W, H, y0, y1, d_rgba8[v], nullptr, nullptr);
+      if (rc) return rc;
+    }
+    return PBR_OK;
+  }
+  if (W <= 0 || H <= 0 || W > 16384 || H > 16384) return fail(c, PBR_E_ARG, "bad target size %dx%d", W, H);
+  if (y0 < 0 || y1 > H || y0 >= y1 || (y0 & 1) || ((y1 & 1) && y1 != H)) return fail(c, PBR_E_ARG, "bad row range [%d,%d) for height %d (rows must start and end on even lines)", y0, y1, H);
+  if (!a->d_vsoa) return fail(c, PBR_E_STATE, "no mesh uploaded");
+  if (!a->d_irr) return fail(c, PBR_E_STATE, "irradiance map not generated");
+  if (!a->d_pre) return fail(c, PBR_E_STATE, "prefilter map not generated");
+  if (!a->d_lut) return fail(c, PBR_E_STATE, "BRDF LUT not generated");
+  if (!a->d_sky) return fail(c, PBR_E_STATE, "skybox cube not generated");
+  if (a->has_instance_mats == false && a->n_instances != 1) return fail(c, PBR_E_STATE, "instanced mesh without instance matrices");
+  DeviceGuard guard(c->device);
+  int rc = PBR_OK;
+  const bool stale = apr->sky_b.dirty || !apr->sky_b.d || apr->irr_b.dirty || !apr->irr_b.d || apr->pre_b.dirty || !apr->pre_b.d || apr->lut_quad_dirty ||
+                     apr->lut_quad_size != a->lut_size || apr->atlas_dirty || !apr->d_atlas;
+  if (stale && (rc = refresh_lookup_copies(c, a, apr, true))) return rc;
+
+  const int rows = y1 - y0;
+  const int tiles_x = (W + PBR_TILE - 1) / PBR_TILE, tiles_y = (rows + PBR_TILE - 1) / PBR_TILE, n_tiles = tiles_x * tiles_y;
+  hipStream_t s = c->stream;
+  while ((int)pr->view_slots.size() < n_views - 1) {
+    PbrContext* slot = nullptr;
+    if ((rc = make_view_slot(c, &slot))) return rc;
+    pr->view_slots.push_back(slot);
+  }
+
+  SkyShare share;
+  share.sky = apr->sky_b.cube; share.rgba8 = nullptr; share.first = 0; share.own_blocks = 0;
+  share.count = std::min(n_tiles, std::max(0, (int)(n_tiles * PBR_SKY_SHARE_SETUP)));
+  ViewArgs views[PBR_MAX_VIEWS];
+  std::memset(views, 0, sizeof views);
+  for (int v = 0; v < n_views; ++v) {
+    PbrContext* w = v == 0 ? c : pr->view_slots[v - 1];   // whose working buffers and counters this view uses
+    PbrContextPrivate* wpr = priv_of(w);
+    w->stream = s;                                        // (a slot's buffers are used, and may only be regrown, in this stream's order)
+    if ((rc = ensure_frame_buffers(w, W, rows, n_tiles, 1, /*outputs=*/false))) return w == c ? rc : fail(c, rc, "%s", w->error.c_str());
+    ViewArgs& va = views[v];
+    FrameParams& fp = va.fp;
+    fp.u = u[v];
+    mat4_mul_host(u[v].projection, u[v].view, fp.pv);
+    fp.W = W; fp.H = H; fp.y0 = y0; fp.y1 = y1; fp.tiles_x = tiles_x; fp.tiles_y = tiles_y;
+    fp.tiles_x_magic = (uint32_t)((0x100000000ull + (uint64_t)tiles_x - 1) / (uint64_t)tiles_x);
+    fp.n_verts = a->n_verts; fp.n_tris = a->n_indices / 3; fp.n_instances = a->n_instances;
+    fp.has_instance_mats = a->has_instance_mats ? 1 : 0;
+    fp.msaa = 0;
+    fp.two_over_w = 2.0f / (float)W; fp.two_over_h = 2.0f / (float)H;
+    sky_affine(u[v].inv_view_proj, W, H, fp);
+    uint32_t* counters = w->d_counters + 8 * wpr->counter_set;
+    uint32_t* next_counters = w->d_counters + 8 * (1 - wpr->counter_set);
+    wpr->counter_set = 1 - wpr->counter_set;
+    const LiveTiles live = {w->d_live_tiles, w->d_live_info, PBR_LIVE_TILE_CAP, ++w->live_serial};
+    BinTargets& bt = va.bt;
+    bt.setup = w->d_setup; bt.setup_cap = (uint32_t)w->setup_cap; bt.tile_count = w->d_tile_count; bt.bins = w->d_bins; bt.overflow = w->d_overflow;
+    bt.overflow_cap = (uint32_t)w->overflow_cap; bt.counters = counters; bt.live = live; bt.records = w->d_records;
+    bt.vsoa = a->d_vsoa; bt.inst_model = a->d_inst_model; bt.inst_normal = a->d_inst_normal;
+    RasterTargets& ra = va.ra;
+    ra.setup = w->d_setup; ra.tile_count = w->d_tile_count; ra.bins = w->d_bins; ra.overflow = w->d_overflow; ra.overflow_cap = (uint32_t)w->overflow_cap;
+    ra.counters = counters; ra.next_counters = next_counters; ra.lists = w->quad_lists; ra.rgba8 = static_cast<uint32_t*>(d_rgba8[v]); ra.live = live;
+    va.records = w->d_records;
+    w->last_w = W; w->last_rows = rows; w->last_samples = 1;
+    ++wpr->frames_drawn;
+  }
+  launch_setup_views(s, views, n_views, a->d_indices, a->n_indices / 3, a->n_instances, share);
+  launch_raster_views(s, views, n_views, apr->sky_b.cube, share.first + share.count, tiles_x, tiles_y, PBR_LIVE_TILE_CAP);
+  ResolveInputs in;
+  in.records = nullptr; in.vout = a->d_vout; in.indices = a->d_indices;
+  for (int i = 0; i < 5; ++i) in.tex[i] = a->tex[i];
+  in.irr = a->irr; in.pre = a->pre; in.sky = a->sky;
+  in.irr_b = apr->irr_b.cube; in.pre_b = apr->pre_b.cube; in.sky_b = apr->sky_b.cube;
+  in.lut = a->d_lut; in.lut_quad = apr->d_lut_quad; in.atlas = apr->d_atlas; in.lut_size = a->lut_size;
+  const bool prof = c->profiling && c->prof_frames < c->prof_cap;
+  hipEvent_t* pe = prof ? &c->prof_events[2 * c->prof_frames] : nullptr;   // the pass's surface launch counts as one profiled frame
+  if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
+  const bool alone = c->parent == nullptr && c->children == 0;
+  launch_surface_views(s, views, n_views, in, pr->d_srgb_lut, pr->surface_blocks, /*shared_chip=*/!alone);
+  if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
+  HIP_TRY(c, hipGetLastError());
+  return PBR_OK;
 }
 
 int pbr_draw_frame_static(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1, void* d_rgba8) {

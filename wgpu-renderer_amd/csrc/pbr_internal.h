@@ -117,6 +117,7 @@ struct FrameParams {
 struct PbrContext {
   int device = 0;
   PbrContext* parent = nullptr;   // set in a forked context: the scene (mesh, textures, IBL maps) is the parent's
+  bool view_slot = false;         // a hidden context that only lends its working buffers to one view of another context's multi-view pass
   int children = 0;               // forks alive
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
@@ -197,6 +198,19 @@ struct VertexSource { const VertexOut* vout; const float* vsoa; const float* ins
 // entries of earlier frames read as "not listed" without anyone clearing them, and the rasteriser's workgroup k
 // learns from the one load of tiles[k] both whether there is a k-th tile and which.
 struct LiveTiles { unsigned long long* tiles; unsigned long long* info; uint32_t cap; unsigned long long serial; };
+// Where the set-up launch appends a front-facing (sub)triangle and references it from every tile its bounding box
+// touches.  A tile keeps its first PBR_BIN_CAP references in its own row of `bins`; any beyond that go to one shared
+// overflow list of (tile, triangle) pairs.
+struct BinTargets {
+  SetupTri* setup; uint32_t setup_cap;
+  uint32_t* tile_count; uint32_t* bins;
+  uint2* overflow; uint32_t overflow_cap;
+  uint32_t* counters;
+  LiveTiles live;
+  TriRecord* records;
+  // when vsoa is set the triangle's vertices are transformed here from the vertex streams (and vout is not read)
+  const float* vsoa; const float* inst_model; const float* inst_normal;
+};
 void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint32_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,
                           const LiveTiles& live, int n_tris, int n_instances, const SkyShare& share);
@@ -238,3 +252,20 @@ void launch_lut_quad(hipStream_t s, const uint16_t* lut_rgba16f, uint4* quad, in
 void launch_material_atlas(hipStream_t s, const uint32_t* const chains[5], uint4* atlas, size_t texels);
 // pixels with at least one covered sample
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n_pixels, int samples, uint32_t* covered);
+
+// ---- several views of one scene in one pass (pbr_draw_views_device) ----
+// Each of the pass's three launches covers all the views: what a view has for itself (its parameters, the memory its
+// frame works in, its colour target) is one ViewArgs on the host, of which every launch takes what it needs as arrays
+// in its kernel arguments, and a workgroup finds its view in its block index.
+#define PBR_MAX_VIEWS 4
+struct RasterTargets {
+  const SetupTri* setup; uint32_t* tile_count; const uint32_t* bins; const uint2* overflow; uint32_t overflow_cap;
+  uint32_t* counters; uint32_t* next_counters; QuadLists lists; uint32_t* rgba8; LiveTiles live;
+};
+struct ViewArgs { FrameParams fp; BinTargets bt; RasterTargets ra; const TriRecord* records; };
+void launch_setup_views(hipStream_t s, const ViewArgs* views, int n_views, const uint32_t* indices, int n_tris, int n_instances, const SkyShare& share);
+void launch_raster_views(hipStream_t s, const ViewArgs* views, int n_views, const DevCubeRgb& sky_bordered, int sky_from_tile, int tiles_x, int tiles_y,
+                         uint32_t live_cap);
+// the surface pass of the specialised pipeline; a single frame is a pass of one view
+void launch_surface_views(hipStream_t s, const ViewArgs* views, int n_views, const ResolveInputs& in, const float* srgb_lut, int resident_blocks,
+                          bool shared_chip);

@@ -101,19 +101,7 @@ PBR_DEV bool setup_bounds(const SetupTri& t, const FrameParams* p, TileBox& box)
   return true;
 }
 
-// Appends a front-facing (sub)triangle to the setup list and references it from every tile its
-// bounding box touches.  A tile keeps its first PBR_BIN_CAP references in its own row of `bins`;
-// any beyond that go to one shared overflow list of (tile, triangle) pairs.
-struct BinTargets {
-  SetupTri* setup; uint32_t setup_cap;
-  uint32_t* tile_count; uint32_t* bins;
-  uint2* overflow; uint32_t overflow_cap;
-  uint32_t* counters;
-  LiveTiles live;
-  TriRecord* records;
-  // when vsoa is set the triangle's vertices are transformed here from the vertex streams (and vout is not read)
-  const float* vsoa; const float* inst_model; const float* inst_normal;
-};
+// (BinTargets, where set-up triangles and tile references go, is declared in pbr_internal.h)
 
 #ifdef PBR_SURFACE_TRACE
 // Diagnostic build only: per workgroup of the set-up launch the 100 MHz timestamps of its start, of its triangles'
@@ -414,6 +402,27 @@ __global__ void __launch_bounds__(256) setup_kernel(const FrameParams frame_para
   SETUP_TRACE(4);
 }
 
+// The same launch for several views of one scene: blockIdx.y is the view, whose parameters and targets are its entries
+// of the argument arrays; the triangles always come from the vertex streams (vout is null; it is a kernel argument,
+// not a literal, because AMD clang 22 of ROCm 7.2 crashes in its control-flow simplification on the literal).
+struct SetupViews { FrameParams fp[PBR_MAX_VIEWS]; BinTargets bt[PBR_MAX_VIEWS]; uint32_t* rgba8[PBR_MAX_VIEWS]; };
+static_assert(sizeof(SetupViews) + sizeof(SkyShare) + 64 <= 4096, "kernel arguments are limited to 4 KB");
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 8)))
+setup_views_kernel(const SetupViews sv, const VertexOut* __restrict__ vout, const uint32_t* __restrict__ indices, int n_tris, int blocks_per_instance,
+                   SkyShare share) {
+  const FrameParams* __restrict__ p = &sv.fp[blockIdx.y];
+  if ((int)blockIdx.x >= share.own_blocks) { sky_tile(p, share.sky, sv.rgba8[blockIdx.y], share.first + (int)blockIdx.x - share.own_blocks); return; }
+  const BinTargets& bt = sv.bt[blockIdx.y];
+  const int inst = (int)blockIdx.x / blocks_per_instance;
+  const int t = ((int)blockIdx.x - inst * blocks_per_instance) * 256 + threadIdx.x;
+  __shared__ BinWindow s_window[4];
+  Pending pending;
+  pending.n_tiles = 0;
+  const bool crosses = t < n_tris && setup_one(p, vout, indices, bt, inst, t, n_tris, pending);
+  bin_wave(p, bt, pending, threadIdx.x & 63, &s_window[threadIdx.x >> 6]);
+  if (crosses) clip_one(p, vout, indices, bt, inst, t, n_tris);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Tile rasteriser.  One 256-thread workgroup owns a 32x32 pixel tile whose depth / id buffer lives
 // in LDS as one 64-bit key per pixel (order-preserving depth bits in the high word, triangle id + 1
@@ -447,19 +456,19 @@ __device__ unsigned long long g_raster_trace[32768][8];
 
 constexpr int kRasterThreads = 256, kRasterWaves = kRasterThreads / 64;
 
-__global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParams frame_params, const SetupTri* __restrict__ setup,
-                                                     uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
-                                                     const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
-                                                     float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters,
-                                                     QuadLists lists, int write_vis, DevCubeRgb sky, uint32_t* __restrict__ rgba8, int sky_from_tile,
-                                                     LiveTiles live, int listed_rows, int listed_parts) {
-  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
+// grid_row: the workgroup's row in its view's grid of (tiles_x, listed_rows + tiles_y) workgroups.
+__device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, const int grid_row, const SetupTri* __restrict__ setup,
+                                            uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
+                                            const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
+                                            float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters,
+                                            const QuadLists& lists, int write_vis, const DevCubeRgb& sky, uint32_t* __restrict__ rgba8, int sky_from_tile,
+                                            const LiveTiles& live, int listed_rows, int listed_parts) {
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
   __shared__ uint32_t s_pairs[kRasterWaves], s_base[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // The frame's append counters come in two sets used by alternate frames; this launch re-arms the set of
   // the next frame, which nothing is using (the previous frame, its last user, finished before this launch began).
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[4] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
+  if (blockIdx.x == 0 && grid_row == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[4] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
   // The first rows of workgroups take the tiles the set-up launch listed as the fullest: the frame waits for
   // those, so they must not queue behind thousands of skybox tiles (the fullest tile of the 4K benchmark frame used to
   // start 7 us into the launch and end it at 38 us).  Every tile also has a workgroup of its own after those, which
@@ -482,11 +491,11 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
   bool clear_count = true;
   uint32_t first_ref = 0u;
   bool have_first_ref = false;
-  if ((int)blockIdx.y < listed_rows) {
+  if (grid_row < listed_rows) {
     // Every memory round trip here is 1.5 - 2 us on the frame's critical path (the launch ends with the fullest of
     // these tiles): one load says whether there is a k-th listed tile and which, and the tile's first references
     // are fetched next to the atomic that returns how many of them count.
-    const uint32_t block = blockIdx.y * gridDim.x + blockIdx.x, parts = (uint32_t)listed_parts, k = parts == 2u ? block >> 1 : block;
+    const uint32_t block = (uint32_t)grid_row * gridDim.x + blockIdx.x, parts = (uint32_t)listed_parts, k = parts == 2u ? block >> 1 : block;
     if (k >= live.cap || parts * k + parts - 1u >= (uint32_t)listed_rows * gridDim.x) return;   // (a lone last workgroup has no partner: the tile's own takes it)
     const unsigned long long listed = live.tiles[k];
     if ((listed >> 24) != live.serial) return;
@@ -501,7 +510,7 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
     clear_count = (s_base[0] >> 30) == parts;
     __syncthreads();   // s_base is used again below
   } else {
-    tile_x = (int)blockIdx.x; tile_y = (int)blockIdx.y - listed_rows;
+    tile_x = (int)blockIdx.x; tile_y = grid_row - listed_rows;
     tile = tile_y * p->tiles_x + tile_x;
     n = tile_count[tile] & kCountMask;
     if (n > PBR_DENSE_TILE_REFS) {
@@ -730,6 +739,40 @@ __global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParam
   }
 }
 
+__global__ void __launch_bounds__(kRasterThreads) raster_kernel(const FrameParams frame_params, const SetupTri* __restrict__ setup,
+                                                     uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ bins,
+                                                     const uint2* __restrict__ overflow, uint32_t overflow_cap, uint32_t* __restrict__ vis,
+                                                     float* __restrict__ depth, uint32_t* __restrict__ counters, uint32_t* __restrict__ next_counters,
+                                                     QuadLists lists, int write_vis, DevCubeRgb sky, uint32_t* __restrict__ rgba8, int sky_from_tile,
+                                                     LiveTiles live, int listed_rows, int listed_parts) {
+  // parameters travel as kernel arguments: no per-frame copy to device memory
+  raster_tile(&frame_params, (int)blockIdx.y, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters, next_counters, lists, write_vis, sky, rgba8,
+              sky_from_tile, live, listed_rows, listed_parts);
+}
+
+// The same launch for several views of one scene.  The grid is (tiles_x, n_views * (listed_rows + tiles_y)): the rows
+// of workgroups that take the views' listed (fullest) tiles come first, view after view, so that no view's fullest
+// tile queues behind another view's thousands of skybox tiles; then the views' own rows.  Neither the visibility nor
+// the depth buffer is written on this path.
+struct RasterViews { FrameParams fp[PBR_MAX_VIEWS]; RasterTargets ra[PBR_MAX_VIEWS]; };
+static_assert(sizeof(RasterViews) + sizeof(DevCubeRgb) + 64 <= 4096, "kernel arguments are limited to 4 KB");
+__global__ void __launch_bounds__(kRasterThreads) raster_views_kernel(const RasterViews rv, int n_views, DevCubeRgb sky, int sky_from_tile, int listed_rows,
+                                                                      int tiles_y) {
+  int row = (int)blockIdx.y, view;
+  const int listed_all = n_views * listed_rows;
+  if (row < listed_all) {
+    view = (row >= listed_rows) + (row >= 2 * listed_rows) + (row >= 3 * listed_rows);   // n_views <= 4: no division
+    row -= view * listed_rows;
+  } else {
+    row -= listed_all;
+    view = (row >= tiles_y) + (row >= 2 * tiles_y) + (row >= 3 * tiles_y);
+    row += listed_rows - view * tiles_y;
+  }
+  const RasterTargets& ra = rv.ra[view];
+  raster_tile(&rv.fp[view], row, ra.setup, ra.tile_count, ra.bins, ra.overflow, ra.overflow_cap, nullptr, nullptr, ra.counters, ra.next_counters, ra.lists, 0,
+              sky, ra.rgba8, sky_from_tile, ra.live, listed_rows, 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The rasteriser of the multisampled pipeline (multisample.count = 4, renderer.ts:492-501): the same
 // tile scheme with four keys per pixel, one per sample point of the standard pattern
@@ -925,4 +968,24 @@ void launch_raster_msaa(hipStream_t s, const FrameParams& p, const SetupTri* set
                         bool write_empty_tiles, int tiles_x, int tiles_y, const LiveTiles& live) {
   hipLaunchKernelGGL(raster_msaa_kernel, dim3(tiles_x, tiles_y), dim3(256), 0, s, p, setup, tile_count, bins, overflow, overflow_cap, vis, depth, counters,
                      next_counters, tile_live, write_empty_tiles ? 1 : 0);
+}
+
+void launch_setup_views(hipStream_t s, const ViewArgs* views, int n_views, const uint32_t* indices, int n_tris, int n_instances, const SkyShare& share_in) {
+  const int per_instance = (n_tris + 255) / 256;
+  SkyShare share = share_in;
+  share.own_blocks = per_instance * n_instances;
+  SetupViews sv = {};
+  for (int v = 0; v < n_views; ++v) { sv.fp[v] = views[v].fp; sv.bt[v] = views[v].bt; sv.rgba8[v] = views[v].ra.rgba8; }
+  hipLaunchKernelGGL(setup_views_kernel, dim3(share.own_blocks + share.count, n_views), dim3(256), 0, s, sv, static_cast<const VertexOut*>(nullptr), indices, n_tris,
+                     per_instance, share);
+}
+
+void launch_raster_views(hipStream_t s, const ViewArgs* views, int n_views, const DevCubeRgb& sky_bordered, int sky_from_tile, int tiles_x, int tiles_y,
+                         uint32_t live_cap) {
+  const int n_tiles = tiles_x * tiles_y, listed_blocks = std::min(n_tiles, (int)live_cap);
+  const int listed_rows = (listed_blocks + tiles_x - 1) / tiles_x;
+  RasterViews rv = {};
+  for (int v = 0; v < n_views; ++v) { rv.fp[v] = views[v].fp; rv.ra[v] = views[v].ra; }
+  hipLaunchKernelGGL(raster_views_kernel, dim3(tiles_x, n_views * (listed_rows + tiles_y)), dim3(kRasterThreads), 0, s, rv, n_views, sky_bordered, sky_from_tile,
+                     listed_rows, tiles_y);
 }

@@ -238,8 +238,8 @@ PBR_DEV V3 quad_bcast3(V3 v) { return v3(quad_bcast<SRC>(v.x), quad_bcast<SRC>(v
 // QUAD_SHARED: the four lanes of the quad show the same triangle; its first lane fetches the record and the other
 // three take it across lanes, a quarter of the bytes through the vector memory path.
 template <bool QUAD_SHARED = false>
-PBR_DEV void load_triangle(const ResolveInputs& in, uint32_t tri_index, int qx, int qy, Tri& t, QuadBary& qb) {
-  const float4* rec = reinterpret_cast<const float4*>(in.records + tri_index);
+PBR_DEV void load_triangle(const TriRecord* __restrict__ records, uint32_t tri_index, int qx, int qy, Tri& t, QuadBary& qb) {
+  const float4* rec = reinterpret_cast<const float4*>(records + tri_index);
   float4 r0, r1, r2, r3, r4, r5, r6, r7, r8;
   if constexpr (QUAD_SHARED) {
     // The other three lanes never use their own values (only the first lane's are read below), so these need no
@@ -475,7 +475,7 @@ PBR_DEV uint32_t shade_quad_lane(const FrameParams* p, const ResolveInputs& in, 
   Tri t;
   QuadBary qb;
   if (id != 0u) {
-    load_triangle(in, id - 1u, qx, qy, t, qb);
+    load_triangle(in.records, id - 1u, qx, qy, t, qb);
     const Varyings h0 = varyings_at(t, qb, qx, qy, 0, 0, p->W, p->H), h1 = varyings_at(t, qb, qx, qy, 1, 0, p->W, p->H),
                    h2 = varyings_at(t, qb, qx, qy, 0, 1, p->W, p->H);
     f = sub == 0 ? h0 : sub == 1 ? h1 : sub == 2 ? h2 : varyings_at(t, qb, qx, qy, 1, 1, p->W, p->H);
@@ -650,8 +650,8 @@ PBR_DEV void tbn_reflect(const FrameParams* p, const V3& T, const Varyings& v, V
 // other three lanes and their values are read across lanes.  Otherwise every covered lane evaluates
 // its own triangle at the pixels (0,0), (1,0), (0,1) of the quad itself.
 template <bool UNIFORM>
-PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveInputs& in, const float* s_srgb, uint32_t* __restrict__ rgba8, int qx,
-                               int qy, uint32_t id, bool live) {
+PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveInputs& in, const TriRecord* __restrict__ records, const float* s_srgb,
+                               uint32_t* __restrict__ rgba8, int qx, int qy, uint32_t id, bool live) {
   const int sub = threadIdx.x & 3;
   const int x = qx + (sub & 1), y = qy + (sub >> 1);
   const bool cov = live && id != 0u;
@@ -661,7 +661,7 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   const uint32_t tri_id = cov ? id - 1u : 0u;
   Tri t;
   QuadBary qb;
-  load_triangle<UNIFORM>(in, tri_id, qx, qy, t, qb);
+  load_triangle<UNIFORM>(records, tri_id, qx, qy, t, qb);
   Varyings f, h0, h1, h2;
   if constexpr (UNIFORM) {
     f = varyings_at(t, qb, qx, qy, sub & 1, sub >> 1, p->W, p->H);
@@ -837,47 +837,90 @@ constexpr int kXcds = 8;
 constexpr int kTraceSlots = 16;
 __device__ unsigned long long g_surface_trace[1024 * 16][kTraceSlots];
 #endif
+// What the views of one pass differ in, as kernel arguments (a single frame is a pass of one view).
+struct SurfaceViews {
+  FrameParams fp[PBR_MAX_VIEWS];
+  const TriRecord* records[PBR_MAX_VIEWS];
+  QuadLists lists[PBR_MAX_VIEWS];
+  uint32_t* rgba8[PBR_MAX_VIEWS];
+  const uint32_t* counters[PBR_MAX_VIEWS];
+};
+static_assert(sizeof(SurfaceViews) + sizeof(ResolveInputs) + 32 <= 4096, "kernel arguments are limited to 4 KB");
+// One launch shades the listed quads of all the views of a pass.  A workgroup takes its stretch of the quad lists of
+// every view, view after view (of each view the mixed quads first), and its waves claim the items of all of them from
+// the one counter: with several views a wave shades more items one after the other, and the launch's fixed costs (its
+// first round of loads into cold caches, its tail) are paid once per pass instead of once per frame.  The stretch a
+// workgroup takes is the same relative piece of every view, so with neighbouring camera positions it stays on the same
+// texels.  Single frames and passes run this same code, so a frame's bytes do not depend on how it was submitted.
 template <int THREADS>
-__global__ void __launch_bounds__(THREADS) resolve_surface_fast_kernel(const FrameParams frame_params, ResolveInputs in, const float* __restrict__ srgb_lut,
-                                                                       uint32_t* __restrict__ rgba8, QuadLists lists, const uint32_t* __restrict__ counters) {
-  const FrameParams* __restrict__ p = &frame_params;   // parameters travel as kernel arguments: no per-frame copy to device memory
+__global__ void __launch_bounds__(THREADS) resolve_surface_fast_kernel(const SurfaceViews sv, int n_views, ResolveInputs in,
+                                                                       const float* __restrict__ srgb_lut) {
   __shared__ float s_srgb[256];
   __shared__ uint32_t s_next;
+  // per view: items of this workgroup in all, its mixed ones, first mixed item, first uniform item, quads in the two lists
+  __shared__ uint32_t s_own[PBR_MAX_VIEWS], s_own_mixed[PBR_MAX_VIEWS], s_m_begin[PBR_MAX_VIEWS], s_u_begin[PBR_MAX_VIEWS], s_n_uniform[PBR_MAX_VIEWS],
+      s_n_mixed[PBR_MAX_VIEWS];
   for (int i = threadIdx.x; i < 256; i += THREADS) s_srgb[i] = srgb_lut[i];
   if (threadIdx.x == 0) s_next = 0u;
+  if ((int)threadIdx.x < PBR_MAX_VIEWS) {
+    const int view = threadIdx.x;
+    uint32_t n_uniform = 0u, n_mixed = 0u;
+    if (view < n_views) { const uint32_t* counters = sv.counters[view]; n_uniform = counters[6]; n_mixed = counters[7]; }
+    const uint32_t items_mixed = (n_mixed + 15u) >> 4, items_uniform = (n_uniform + 15u) >> 4;
+    // gridDim.x is a multiple of kXcds; v runs over the workgroups XCD by XCD
+    const uint32_t per_xcd = gridDim.x / kXcds, v = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds, nv = gridDim.x;
+    const uint32_t m_begin = (uint32_t)((unsigned long long)items_mixed * v / nv), m_end = (uint32_t)((unsigned long long)items_mixed * (v + 1) / nv);
+    const uint32_t u_begin = (uint32_t)((unsigned long long)items_uniform * v / nv), u_end = (uint32_t)((unsigned long long)items_uniform * (v + 1) / nv);
+    s_own_mixed[view] = m_end - m_begin; s_own[view] = (m_end - m_begin) + (u_end - u_begin);
+    s_m_begin[view] = m_begin; s_u_begin[view] = u_begin; s_n_uniform[view] = n_uniform; s_n_mixed[view] = n_mixed;
+  }
   __syncthreads();
-  const uint32_t n_uniform = counters[6], n_mixed = counters[7];
-  const uint32_t items_mixed = (n_mixed + 15u) >> 4, items_uniform = (n_uniform + 15u) >> 4;
-  // gridDim.x is a multiple of kXcds; v runs over the workgroups XCD by XCD
-  const uint32_t per_xcd = gridDim.x / kXcds, v = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds, nv = gridDim.x;
-  const uint32_t m_begin = (uint32_t)((unsigned long long)items_mixed * v / nv), m_end = (uint32_t)((unsigned long long)items_mixed * (v + 1) / nv);
-  const uint32_t u_begin = (uint32_t)((unsigned long long)items_uniform * v / nv), u_end = (uint32_t)((unsigned long long)items_uniform * (v + 1) / nv);
-  const uint32_t own_mixed = m_end - m_begin, own = own_mixed + (u_end - u_begin);
+  // every wave keeps the views' figures in scalar registers (read once from LDS) and picks its item's by comparisons
+  auto uniform_u32 = [](const uint32_t* lds) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*lds); };
+  struct PerView { uint32_t own, own_mixed, m_begin, u_begin, n_uniform, n_mixed; };
+  PerView pv[PBR_MAX_VIEWS];
+#pragma unroll
+  for (int v = 0; v < PBR_MAX_VIEWS; ++v) {
+    pv[v] = PerView{0u, 0u, 0u, 0u, 0u, 0u};
+    if (v < n_views)   // (a single frame reads one view's six figures, not four views')
+      pv[v] = PerView{uniform_u32(&s_own[v]), uniform_u32(&s_own_mixed[v]), uniform_u32(&s_m_begin[v]), uniform_u32(&s_u_begin[v]), uniform_u32(&s_n_uniform[v]),
+                      uniform_u32(&s_n_mixed[v])};
+  }
+  const uint32_t own0 = pv[0].own, own1 = pv[1].own, own2 = pv[2].own, own3 = pv[3].own;
+  const uint32_t own_all = own0 + own1 + own2 + own3;
   const int lane = threadIdx.x & 63;
 #ifdef PBR_SURFACE_TRACE
   unsigned long long* trace = g_surface_trace[(blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)) % (1024 * 16)];
   int trace_n = 2;
-  if (lane == 0) { trace[0] = wall_clock64(); trace[1] = ((unsigned long long)blockIdx.x << 32) | (own_mixed << 16) | own; }
+  if (lane == 0) { trace[0] = wall_clock64(); trace[1] = ((unsigned long long)blockIdx.x << 32) | (pv[0].own_mixed << 16) | own_all; }
 #endif
   for (;;) {
     uint32_t k = 0;
     if (lane == 0) k = atomicAdd(&s_next, 1u);
     k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k);
-    if (k >= own) break;
-    if (k >= own_mixed) {
-      const uint32_t q = (u_begin + k - own_mixed) * 16u + (uint32_t)(lane >> 2);
-      const bool live = q < n_uniform;
-      const uint2 e = lists.uniform[live ? q : 0u];
-      surface_fast_quad<true>(p, in, s_srgb, rgba8, (int)(e.x & 0xffffu) * 2, p->y0 + (int)(e.x >> 16) * 2, e.y, live);
+    if (k >= own_all) break;
+    int view = 0;
+    if (k >= own0) { k -= own0; view = 1; if (k >= own1) { k -= own1; view = 2; if (k >= own2) { k -= own2; view = 3; } } }
+    auto pick = [&](uint32_t a, uint32_t b, uint32_t c, uint32_t d) { return view == 0 ? a : view == 1 ? b : view == 2 ? c : d; };
+    const FrameParams* __restrict__ p = &sv.fp[view];   // parameters travel as kernel arguments: no per-frame copy to device memory
+    const TriRecord* __restrict__ records = sv.records[view];   // (in.records is not used on this path)
+    uint32_t* __restrict__ rgba8 = sv.rgba8[view];
+    const uint32_t own_mixed = pick(pv[0].own_mixed, pv[1].own_mixed, pv[2].own_mixed, pv[3].own_mixed);
+    const bool uniform_item = k >= own_mixed;
+    if (uniform_item) {
+      const uint32_t q = (pick(pv[0].u_begin, pv[1].u_begin, pv[2].u_begin, pv[3].u_begin) + k - own_mixed) * 16u + (uint32_t)(lane >> 2);
+      const bool live = q < pick(pv[0].n_uniform, pv[1].n_uniform, pv[2].n_uniform, pv[3].n_uniform);
+      const uint2 e = sv.lists[view].uniform[live ? q : 0u];
+      surface_fast_quad<true>(p, in, records, s_srgb, rgba8, (int)(e.x & 0xffffu) * 2, p->y0 + (int)(e.x >> 16) * 2, e.y, live);
     } else {
-      const uint32_t q = (m_begin + k) * 16u + (uint32_t)(lane >> 2);
-      const bool live = q < n_mixed;
-      const uint32_t pos = lists.mixed_pos[live ? q : 0u];
-      const uint32_t id = reinterpret_cast<const uint32_t*>(lists.mixed_ids)[(live ? q : 0u) * 4u + (uint32_t)(lane & 3)];
-      surface_fast_quad<false>(p, in, s_srgb, rgba8, (int)(pos & 0xffffu) * 2, p->y0 + (int)(pos >> 16) * 2, id, live);
+      const uint32_t q = (pick(pv[0].m_begin, pv[1].m_begin, pv[2].m_begin, pv[3].m_begin) + k) * 16u + (uint32_t)(lane >> 2);
+      const bool live = q < pick(pv[0].n_mixed, pv[1].n_mixed, pv[2].n_mixed, pv[3].n_mixed);
+      const uint32_t pos = sv.lists[view].mixed_pos[live ? q : 0u];
+      const uint32_t id = reinterpret_cast<const uint32_t*>(sv.lists[view].mixed_ids)[(live ? q : 0u) * 4u + (uint32_t)(lane & 3)];
+      surface_fast_quad<false>(p, in, records, s_srgb, rgba8, (int)(pos & 0xffffu) * 2, p->y0 + (int)(pos >> 16) * 2, id, live);
     }
 #ifdef PBR_SURFACE_TRACE
-    if (lane == 0 && trace_n < kTraceSlots) trace[trace_n] = (wall_clock64() << 1) | (k >= own_mixed ? 1ull : 0ull);
+    if (lane == 0 && trace_n < kTraceSlots) trace[trace_n] = (wall_clock64() << 1) | (uniform_item ? 1ull : 0ull);
     ++trace_n;
 #endif
   }
@@ -1005,18 +1048,29 @@ void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in
                     const QuadLists& lists, const uint32_t* counters, int W, int rows, int tiles_x, int tiles_y, bool fast, int resident_blocks, bool shared_chip) {
   uint32_t* out = reinterpret_cast<uint32_t*>(rgba8);
   if (fast) {
-    // as many workgroups as the chip holds at once, a multiple of the XCD count
-    const int blocks = std::max(kXcds, resident_blocks / kXcds * kXcds);
-    if (shared_chip) {
-      const int small = std::max(kXcds, resident_blocks / std::max(1, surface_fast_blocks_per_cu()) * kSurfaceSmallPerCu / kXcds * kXcds);
-      hipLaunchKernelGGL(resolve_surface_fast_kernel<kSurfaceSmallThreads>, dim3(small), dim3(kSurfaceSmallThreads), 0, s, p, in, srgb_lut, out, lists, counters);
-    } else {
-      hipLaunchKernelGGL(resolve_surface_fast_kernel<kSurfaceThreads>, dim3(blocks), dim3(kSurfaceThreads), 0, s, p, in, srgb_lut, out, lists, counters);
-    }
+    ViewArgs one = {};   // a single frame is a pass of one view
+    one.fp = p; one.records = in.records; one.ra.lists = lists; one.ra.rgba8 = out; one.ra.counters = const_cast<uint32_t*>(counters);
+    launch_surface_views(s, &one, 1, in, srgb_lut, resident_blocks, shared_chip);
   } else {
     const int per_cu = std::max(1, general_blocks_per_cu());
     const int blocks = std::max(kXcds, (resident_blocks / std::max(1, surface_fast_blocks_per_cu())) * per_cu / kXcds * kXcds);
     hipLaunchKernelGGL(resolve_surface_lists_kernel, dim3(blocks), dim3(kGeneralThreads), 0, s, p, in, srgb_lut, out, lists, counters);
+  }
+}
+
+void launch_surface_views(hipStream_t s, const ViewArgs* views, int n_views, const ResolveInputs& in, const float* srgb_lut, int resident_blocks,
+                          bool shared_chip) {
+  SurfaceViews sv = {};
+  for (int v = 0; v < n_views; ++v) {
+    sv.fp[v] = views[v].fp; sv.records[v] = views[v].records; sv.lists[v] = views[v].ra.lists; sv.rgba8[v] = views[v].ra.rgba8; sv.counters[v] = views[v].ra.counters;
+  }
+  // as many workgroups as the chip holds at once, a multiple of the XCD count
+  const int blocks = std::max(kXcds, resident_blocks / kXcds * kXcds);
+  if (shared_chip) {
+    const int small = std::max(kXcds, resident_blocks / std::max(1, surface_fast_blocks_per_cu()) * kSurfaceSmallPerCu / kXcds * kXcds);
+    hipLaunchKernelGGL(resolve_surface_fast_kernel<kSurfaceSmallThreads>, dim3(small), dim3(kSurfaceSmallThreads), 0, s, sv, n_views, in, srgb_lut);
+  } else {
+    hipLaunchKernelGGL(resolve_surface_fast_kernel<kSurfaceThreads>, dim3(blocks), dim3(kSurfaceThreads), 0, s, sv, n_views, in, srgb_lut);
   }
 }
 

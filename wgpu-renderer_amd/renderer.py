@@ -215,6 +215,19 @@ class Renderer:
         self._check(self._lib.pbr_draw_frame_device(self._ctx, C.byref(u), self.width, self.height, y0, y1, C.c_void_p(d_rgba8),
                                                     C.c_void_p(d_vis) if d_vis else None, C.byref(stats) if stats is not None else None))
 
+    def draw_views_device(self, uniforms, d_rgba8, y0=0, y1=None):
+        """Several frames of the scene in one pass: view v is drawn with uniforms[v] into device address d_rgba8[v]
+        (one to four views); every target gets the bytes draw_frame_device would have given it."""
+        if not self._ready:
+            self.init()
+        y1 = self.height if y1 is None else y1
+        n = len(uniforms)
+        if n != len(d_rgba8):
+            raise ValueError("one colour target per view")
+        us = (_lib.FrameUniforms * n)(*uniforms)
+        outs = (C.c_void_p * n)(*[C.c_void_p(int(a)) for a in d_rgba8])
+        self._check(self._lib.pbr_draw_views_device(self._ctx, n, us, self.width, self.height, y0, y1, outs))
+
     def render(self):
         """renderer.ts:102-105: init then run; headless `run` is one frame, returned as RGBA8."""
         if not self._ready:
