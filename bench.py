@@ -64,6 +64,10 @@ def measured_traffic(kernel):
             table = json.load(f)
         if kernel in table:
             return float(table[kernel]["hbm_bytes"])
+        if "<" in kernel and not any(k.startswith(kernel.split("<")[0] + "<") for k in table):
+            kernel = kernel.split("<")[0]           # a table that does not tell the instantiations apart
+            if kernel in table:
+                return float(table[kernel]["hbm_bytes"])
         # a templated kernel is listed once per instantiation ("name<256>", "name<1024>"): the one launched most often
         # in the measured run is the one the timed region launches
         shapes = [v for k, v in table.items() if k.startswith(kernel + "<")]
@@ -72,9 +76,25 @@ def measured_traffic(kernel):
         return None
 
 
-def measured_frame_traffic():
-    parts = [measured_traffic(k) for k in FRAME_KERNELS]
-    return None if any(p is None for p in parts) else float(sum(parts))
+def surface_shape(contexts_in_flight):
+    """Name of the surface kernel's instantiation the library launches: small workgroups for a context with forks."""
+    return "resolve_surface_fast_kernel<%d>" % (256 if contexts_in_flight > 1 else 1024)
+
+
+def pass_kernels(views, contexts_in_flight):
+    """The three launches of a pass of `views` frames as the traffic table names them."""
+    if views > 1:
+        return ["setup_views_kernel", "raster_views_kernel", surface_shape(contexts_in_flight)]
+    return ["setup_kernel", "raster_kernel", surface_shape(contexts_in_flight)]
+
+
+def measured_frame_traffic(views=1, contexts_in_flight=2):
+    """HBM-side bytes per frame: the pass's three launches, divided by the frames a pass draws."""
+    parts = [measured_traffic(k) for k in pass_kernels(views, contexts_in_flight)]
+    if any(p is None for p in parts):   # a table from before the kernels had these names
+        parts = [measured_traffic(k) for k in FRAME_KERNELS]
+        views = 1
+    return None if any(p is None for p in parts) else float(sum(parts)) / views
 
 
 def valu_issue(kernels, ms):
@@ -355,8 +375,8 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
         single_frame_ms = lone_span.value / max(lone_frames.value - 1, 1)
         lone_ms = lone_total.value / max(lone_frames.value, 1)
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
-        frame_traffic = measured_frame_traffic()
-        surf_traffic = measured_traffic("resolve_surface_fast_kernel")
+        frame_traffic = measured_frame_traffic(V, K)
+        surf_traffic = measured_traffic(surface_shape(K))   # per launch, i.e. for the V views of a pass, in the shape of the timed region
         issue_one = valu_issue(["resolve_surface_fast_kernel"], iso_ms / V)   # the committed counts are per frame
         issue_frame = valu_issue(FRAME_KERNELS, frame_ms)
         result = {
@@ -383,7 +403,7 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
             # the launch duration is the kernel's alone (nothing else on the chip); inside the timed region the same
             # kernel shares the chip with the other frames' kernels and its event-to-event time is longer than a step
             "roofline": {"bound": "hbm", "kernel": "resolve_surface_fast_kernel", "launch_ms": iso_ms, "achieved": iso_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": iso_gbs / HBM_PEAK_GBS, "traffic": None if surf_traffic is None else V * surf_traffic, "algorithmic_bytes": surf_bytes, "views_per_launch": V,
+                         "frac": iso_gbs / HBM_PEAK_GBS, "traffic": surf_traffic, "algorithmic_bytes": surf_bytes, "views_per_launch": V,
                          "bound_measured": "latency of dependent load rounds at four waves per SIMD; busiest unit: vector issue", "valu_issue": issue_one,
                          "lone_context": {"launch_ms": lone_ms, "achieved": surf_bytes_frame / (lone_ms * 1e-3) / 1e9, "frac": surf_bytes_frame / (lone_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                           "note": "one frame per launch, in the kernel's other shape (one 1024-thread workgroup per compute unit), which the library launches for a context without forks"},

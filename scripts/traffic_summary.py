@@ -16,7 +16,7 @@ rd, n_rd = load(sys.argv[1])
 wr, n_wr = load(sys.argv[2])
 out = {}
 for k in rd:
-    if not any(s in k for s in ("vertex_kernel", "setup_kernel", "raster_kernel", "resolve_surface")):
+    if not any(s in k for s in ("vertex_kernel", "setup_kernel", "setup_views_kernel", "raster_kernel", "raster_views_kernel", "resolve_surface")):
         continue
     r, w = rd[k], wr.get(k, {})
     n32, n64, n128, n = r.get("TCC_EA0_RDREQ_32B_sum", 0), r.get("TCC_EA0_RDREQ_64B_sum", 0), r.get("TCC_EA0_RDREQ_128B_sum", 0), r.get("TCC_EA0_RDREQ_sum", 0)
