@@ -76,15 +76,16 @@ def measured_traffic(kernel):
         return None
 
 
-def surface_shape(contexts_in_flight):
-    """Name of the surface kernel's instantiation the library launches: small workgroups for a context with forks."""
-    return "resolve_surface_fast_kernel<%d>" % (256 if contexts_in_flight > 1 else 1024)
+def surface_shape(contexts_in_flight, views=1):
+    """Name of the surface kernel's instantiation the library launches: small workgroups for the single frames of a
+    context with forks, large ones for a context on its own and for every pass of several views."""
+    return "resolve_surface_fast_kernel<%d>" % (256 if contexts_in_flight > 1 and views == 1 else 1024)
 
 
 def pass_kernels(views, contexts_in_flight):
     """The three launches of a pass of `views` frames as the traffic table names them."""
     if views > 1:
-        return ["setup_views_kernel", "raster_views_kernel", surface_shape(contexts_in_flight)]
+        return ["setup_views_kernel", "raster_views_kernel", surface_shape(contexts_in_flight, views)]
     return ["setup_kernel", "raster_kernel", surface_shape(contexts_in_flight)]
 
 
@@ -133,6 +134,8 @@ def parse_args(argv=None):
                     help="frames in flight per GPU: one renderer context plus forks of it, each on its own stream, take the rank's frames in turn")
     ap.add_argument("--views", type=int, default=4,
                     help="frames per pass: each context draws this many consecutive frames of the orbit with one pbr_draw_views_device call (1..4)")
+    ap.add_argument("--passes-only", action="store_true",
+                    help="for counter runs: skip the single-frame measurements after the timed region, so that every launch of the frame kernels in the run is a whole pass")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the IBL prefilter timing (2048^2, 10 mips)")
     ap.add_argument("--prefilter-size", type=int, default=2048)
@@ -342,13 +345,16 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
     for rr, _, _ in lanes[1:]:
         rr.close()
     lanes = lanes[:1]
-    lone_frames, lone_total, lone_span = isolated(min(args.steps, 20), 1)
+    if args.passes_only:
+        lone_frames, lone_total, lone_span = C.c_int32(0), C.c_float(float("nan")), C.c_float(float("nan"))
+    else:
+        lone_frames, lone_total, lone_span = isolated(min(args.steps, 20), 1)
 
     # coverage for the bandwidth model: sampled on a second pass over a tenth of the timed views (a
     # statistics call synchronises, so it stays out of the timed region)
     stats = pkg._lib.FrameStats()
     cov_sum, tri_sum, n_cov = 0.0, 0, 0
-    for i in range(args.warmup, args.warmup + args.steps, max(1, args.steps // 10)):
+    for i in ([] if args.passes_only else range(args.warmup, args.warmup + args.steps, max(1, args.steps // 10))):
         r.draw_frame_device(lanes[0][2][0].data_ptr(), uniforms=uniforms[i], stats=stats)
         cov_sum += stats.covered_pixels / float(W * H)
         tri_sum += stats.setup_triangles
@@ -376,7 +382,7 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
         lone_ms = lone_total.value / max(lone_frames.value, 1)
         frame_gbs = frame_bytes / (frame_ms * 1e-3) / 1e9
         frame_traffic = measured_frame_traffic(V, K)
-        surf_traffic = measured_traffic(surface_shape(K))   # per launch, i.e. for the V views of a pass, in the shape of the timed region
+        surf_traffic = measured_traffic(surface_shape(K, V))   # per launch, i.e. for the V views of a pass, in the shape of the timed region
         issue_one = valu_issue(["resolve_surface_fast_kernel"], iso_ms / V)   # the committed counts are per frame
         issue_frame = valu_issue(FRAME_KERNELS, frame_ms)
         result = {

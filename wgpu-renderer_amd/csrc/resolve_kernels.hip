@@ -1058,6 +1058,12 @@ void launch_surface(hipStream_t s, const FrameParams& p, const ResolveInputs& in
   }
 }
 
+// A pass of several views gets the large shape even when other passes are in flight: its launch is long enough to fill
+// the chip by itself (4 views: 86 us against 100 us in the small shape, measured alone), and with whole passes in
+// flight the frame time no longer depends on the shape (50.4 against 50.3 us per 4K frame, three passes of four views).
+#ifndef PBR_LARGE_SHAPE_FROM_VIEWS
+#define PBR_LARGE_SHAPE_FROM_VIEWS 2
+#endif
 void launch_surface_views(hipStream_t s, const ViewArgs* views, int n_views, const ResolveInputs& in, const float* srgb_lut, int resident_blocks,
                           bool shared_chip) {
   SurfaceViews sv = {};
@@ -1066,7 +1072,7 @@ void launch_surface_views(hipStream_t s, const ViewArgs* views, int n_views, con
   }
   // as many workgroups as the chip holds at once, a multiple of the XCD count
   const int blocks = std::max(kXcds, resident_blocks / kXcds * kXcds);
-  if (shared_chip) {
+  if (shared_chip && n_views < PBR_LARGE_SHAPE_FROM_VIEWS) {
     const int small = std::max(kXcds, resident_blocks / std::max(1, surface_fast_blocks_per_cu()) * kSurfaceSmallPerCu / kXcds * kXcds);
     hipLaunchKernelGGL(resolve_surface_fast_kernel<kSurfaceSmallThreads>, dim3(small), dim3(kSurfaceSmallThreads), 0, s, sv, n_views, in, srgb_lut);
   } else {
