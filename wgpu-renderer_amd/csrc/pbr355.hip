@@ -431,6 +431,12 @@ struct FrameWork {
 #ifndef PBR_SKY_SHARE_SETUP_ALONE
 #define PBR_SKY_SHARE_SETUP_ALONE 0.55f
 #endif
+// The share for the passes of several views (pbr_draw_views_device): their launches each fill the chip, and a short
+// set-up launch lets the next pass start under the tail of this one (49.4 / 49.5 / 50.3 / 50.4 / 51.5 / 52.6 / 53.8 us
+// per 4K frame at 0 / 0.10 / 0.20 / 0.35 / 0.50 / 0.65 / 0.80, three passes of four views in flight).
+#ifndef PBR_SKY_SHARE_SETUP_PASS
+#define PBR_SKY_SHARE_SETUP_PASS 0.10f
+#endif
 static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, int y0, int y1, void* d_rgba8, void* d_vis, bool want_host_vis,
                        PbrFrameStats* stats, bool static_memory = false) {
   PbrContext* a = assets_of(c);              // scene data may belong to the context this one was forked from
@@ -1169,7 +1175,7 @@ int pbr_draw_views_device(PbrContext* c, int32_t n_views, const PbrFrameUniforms
 
   SkyShare share;
   share.sky = apr->sky_b.cube; share.rgba8 = nullptr; share.first = 0; share.own_blocks = 0;
-  share.count = std::min(n_tiles, std::max(0, (int)(n_tiles * PBR_SKY_SHARE_SETUP)));
+  share.count = std::min(n_tiles, std::max(0, (int)(n_tiles * PBR_SKY_SHARE_SETUP_PASS)));
   ViewArgs views[PBR_MAX_VIEWS];
   std::memset(views, 0, sizeof views);
   for (int v = 0; v < n_views; ++v) {
