@@ -133,3 +133,41 @@ def test_views_from_a_fork_and_at_4k():
             fork.close()
     finally:
         r.close()
+
+
+def test_views_report_and_repair_working_buffer_overflow():
+    """A camera inside a 3 x 3 grid of helmets with every view's set-up buffer and tile-reference list forced far too
+    small: the queued pass is reported incomplete by the next synchronize (whichever view overflowed), the buffers are
+    enlarged, and a pass drawn after that equals its single frames."""
+    import torch
+    pkg = pu._pkg()
+    lib = pkg._lib
+    g = pkg.glTFLoader(); g.load(pkg.renderer.DEFAULT_MODEL)
+    base = g.get_geometries()[0].model
+    models = np.stack([pkg.mathx.mul(pkg.mathx.translate(pkg.mathx.identity(), [(i - 1) * 2.5, (j - 1) * 2.5, 0.0]), base) for j in range(3) for i in range(3)])
+    scene = pu.SmallScene.build(width=480, height=270, instance_models=models)
+    r = scene.renderer
+    try:
+        r.camera.update_camera_distance(430.0, 0.0)          # inside the centre helmet
+        r.camera.update_camera_rotation(-300.0, 150.0)
+        us = _orbit_uniforms(scene, 3, step=-40.0)
+        want = [_single(scene, u, 480, 270, 0, 270) for u in us]
+        got = _views(scene, us, 480, 270, 0, 270)            # creates the views' buffers, with the library's own sizing
+        for v in range(3):
+            assert (got[v] == want[v]).all(), v
+        lib.check(r._ctx, r._lib.pbr_debug_set_capacity(r._ctx, 1500, 64))
+        reported = 0
+        for attempt in range(8):                              # one buffer of one view is enlarged per report
+            try:
+                got = _views(scene, us, 480, 270, 0, 270)
+                break
+            except lib.PbrError as e:
+                assert "draw it again" in str(e)
+                reported += 1
+        else:
+            raise AssertionError("the pass never completed")
+        assert reported >= 2                                  # at least view 0 and one further view overflowed
+        for v in range(3):
+            assert (got[v] == want[v]).all(), ("after the repair", v)
+    finally:
+        r.close()

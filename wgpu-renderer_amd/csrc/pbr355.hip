@@ -1119,6 +1119,7 @@ static int make_view_slot(PbrContext* c, PbrContext** out) {
   if (rc) return fail(c, rc, "%s", pbr_last_error(nullptr));
   slot->parent = assets_of(c);
   slot->view_slot = true;
+  slot->forced_setup_cap = c->forced_setup_cap; slot->forced_overflow_cap = c->forced_overflow_cap;   // (test hook: pbr_debug_set_capacity)
   *out = slot;
   return PBR_OK;
 }
@@ -1266,6 +1267,10 @@ int pbr_debug_set_capacity(PbrContext* c, size_t setup_triangles, size_t overflo
   if (!c) return PBR_E_ARG;
   c->forced_setup_cap = setup_triangles; c->forced_overflow_cap = overflow_refs;
   c->min_setup_cap = 0; c->min_overflow_cap = 0;
+  for (PbrContext* slot : priv_of(c)->view_slots) {   // the views of a pass each work in buffers of their own
+    slot->forced_setup_cap = setup_triangles; slot->forced_overflow_cap = overflow_refs;
+    slot->min_setup_cap = 0; slot->min_overflow_cap = 0;
+  }
   return PBR_OK;
 }
 
