@@ -246,8 +246,9 @@ prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, i
   // the two scale factors of equirectangular.wgsl:2 held in vector registers (see the note on issue rates above)
   float inv_atan_x = INV_ATAN_X, inv_atan_y = INV_ATAN_Y;
   asm volatile("" : "+v"(inv_atan_x), "+v"(inv_atan_y));
-  for (int i = sub; i < n_samples; i += SPLIT) {
-    float lx, ly, lz, wa, wc, w0f, h0f;
+  // Where sample i reads: its two source pixels and their weights.
+  auto locate = [&](int i, const float*& qa, const float*& qc, float& wa, float& wc) {
+    float lx, ly, lz, w0f, h0f;
     int l0, l1;
     if constexpr (SPLIT == 1) {
       const float4 dir = s_table[2 * i], rest = s_table[2 * i + 1];
@@ -283,9 +284,34 @@ prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, i
       i0 = (uint32_t)y0 * (uint32_t)w0 + (uint32_t)x0; i1 = (uint32_t)y1 * (uint32_t)w1 + (uint32_t)x1;
     }
     // (the level's start is added to the pointer, where it is scalar arithmetic, not to the per-lane index)
-    const float* qa = hdr.rgb + 3 * (size_t)hdr.off[l0] + 3 * (size_t)i0;
-    const float* qc = hdr.rgb + 3 * (size_t)hdr.off[l1] + 3 * (size_t)i1;
-    const V3 a = v3(qa[0], qa[1], qa[2]), c = v3(qc[0], qc[1], qc[2]);   // one 12-byte load each
+    qa = hdr.rgb + 3 * (size_t)hdr.off[l0] + 3 * (size_t)i0;
+    qc = hdr.rgb + 3 * (size_t)hdr.off[l1] + 3 * (size_t)i1;
+  };
+  // Several samples at a time: the samples' source pixels are located first and their 12-byte loads issued together,
+  // so that a wavefront has several times the requests in flight (the kernel's time is the latency of the requests that
+  // leave L1, at full occupancy); the sums take the samples in their order.  2048^2 x 10 levels: 16.9 ms one sample at a
+  // time, 15.7 / 15.15 / 15.5 / 17.1 ms in groups of 2 / 3 / 4 / 6 (45 / 60 / 66 / 66 registers: beyond 64 a SIMD holds 7 waves).
+#ifndef PBR_PREFILTER_GROUP
+#define PBR_PREFILTER_GROUP 3
+#endif
+  constexpr int kGroup = PBR_PREFILTER_GROUP;
+  int i = sub;
+  for (; i + (kGroup - 1) * SPLIT < n_samples; i += kGroup * SPLIT) {
+    const float *qa[kGroup], *qc[kGroup];
+    float wa[kGroup], wc[kGroup];
+    V3 a[kGroup], c[kGroup];
+#pragma unroll
+    for (int k = 0; k < kGroup; ++k) locate(i + k * SPLIT, qa[k], qc[k], wa[k], wc[k]);
+#pragma unroll
+    for (int k = 0; k < kGroup; ++k) { a[k] = v3(qa[k][0], qa[k][1], qa[k][2]); c[k] = v3(qc[k][0], qc[k][1], qc[k][2]); }   // one 12-byte load each
+#pragma unroll
+    for (int k = 0; k < kGroup; ++k) { r += a[k].x * wa[k] + c[k].x * wc[k]; g += a[k].y * wa[k] + c[k].y * wc[k]; b += a[k].z * wa[k] + c[k].z * wc[k]; }
+  }
+  for (; i < n_samples; i += SPLIT) {
+    const float *qa, *qc;
+    float wa, wc;
+    locate(i, qa, qc, wa, wc);
+    const V3 a = v3(qa[0], qa[1], qa[2]), c = v3(qc[0], qc[1], qc[2]);
     r += a.x * wa + c.x * wc; g += a.y * wa + c.y * wc; b += a.z * wa + c.z * wc;
   }
 #pragma unroll
