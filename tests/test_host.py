@@ -232,7 +232,7 @@ def test_prefilter_shards_carry_equal_cost(pkg):
 
     def factors(m):   # (side faces, +-Y faces)
         r = m / (mips - 1)
-        return (1.0, 1.0) if m == 0 else (1.0, 1.60) if r <= 0.17 else (1.32, 1.87) if r <= 0.28 else (1.37, 1.44)
+        return (1.0, 1.0) if m == 0 else (1.0, 1.41) if r <= 0.17 else (1.24, 2.07) if r <= 0.28 else (1.37, 1.44)
 
     segments = []     # (first texel, texel count, cost per texel, samples per texel) of every face of every level
     first = 0

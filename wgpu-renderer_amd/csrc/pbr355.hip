@@ -179,9 +179,10 @@ float prefilter_roughness(int level, int mips) { return mips > 1 ? (float)((doub
 // price of its two source-pixel gathers and was measured on MI355X (2048^2 x 10 levels from a 4096 x 2048 source,
 // every face of every level filtered on its own, scripts/gpu_prefilter_shards.py):
 //   * the +-Y faces look at the pole rows of the equirect image, where a block of neighbouring directions is
-//     stretched over many more pixels of a row (more cache lines per wavefront load): 1.6 x the other faces at
-//     the smoothest filtered level, whose samples read the finest source levels, 1.4 x at the next, 1.05 x beyond;
-//   * rougher levels scatter their samples wider and are smaller launches: 1.32 x and 1.37 x per sample.
+//     stretched over many more pixels of a row (more cache lines per wavefront load): 1.41 x the other faces at
+//     the smoothest filtered level, whose samples read the finest source levels, 1.67 x at the next, 1.05 x beyond;
+//   * rougher levels scatter their samples wider and are smaller launches: 1.24 x and 1.37 x per sample.
+// (Re-measured with the kernel that takes its samples three at a time; the kernel before it had 1.6 / 1.4 and 1.32.)
 // Only the balance of the shards depends on these numbers, never a result.
 constexpr uint64_t PREFILTER_TEXEL_OVERHEAD = 8;
 struct PrefilterCost { int kept[PBR_MAX_LEVELS]; uint64_t per_texel[PBR_MAX_LEVELS][6]; };
@@ -192,8 +193,8 @@ void prefilter_costs(int mips, PrefilterCost* pc) {
     const float roughness = prefilter_roughness(m, mips);
     const int n = build_prefilter_table(roughness, PBR_MAX_LEVELS, table.data(), &weight);   // the count does not depend on the source's level count
     pc->kept[m] = n;
-    const uint64_t side = roughness == 0.0f ? 100 : roughness <= 0.17f ? 100 : roughness <= 0.28f ? 132 : 137;   // per sample, in hundredths
-    const uint64_t pole = roughness == 0.0f ? 100 : roughness <= 0.17f ? 160 : roughness <= 0.28f ? 187 : 144;
+    const uint64_t side = roughness == 0.0f ? 100 : roughness <= 0.17f ? 100 : roughness <= 0.28f ? 124 : 137;   // per sample, in hundredths
+    const uint64_t pole = roughness == 0.0f ? 100 : roughness <= 0.17f ? 141 : roughness <= 0.28f ? 207 : 144;
     for (int f = 0; f < 6; ++f) pc->per_texel[m][f] = ((uint64_t)n + PREFILTER_TEXEL_OVERHEAD) * ((f == 2 || f == 3) ? pole : side);
   }
 }
