@@ -520,7 +520,7 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
                      "reference_samples": texels * 1024, "reference_gsamples_per_s": texels * 1024 / (ms * 1e-3) / 1e9,
                      # work executed: roughness 0 collapses to one sample per texel and samples with N.L <= 0 contribute nothing
                      "executed_samples": executed, "executed_gsamples_per_s": executed / (ms * 1e-3) / 1e9, "kept_samples_per_level": kept,
-                     "bound_measured": "two 12-byte gathers per sample: texture-address units 75 % busy, every gather misses L1 (5 L2 requests per wavefront load); see profiles/r02_prefilter_counters.txt"})
+                     "bound_measured": "latency of the requests that leave L1 (two 12-byte gathers per sample, 5 L2 requests per wavefront load) times the loads a compute unit keeps in flight; texture-address units three quarters busy; see profiles/r02_prefilter_counters.txt"})
     except Exception as exc:                             # the frame benchmark above stands on its own
         info["error"] = f"{type(exc).__name__}: {exc}"
     if rank == 0 and result is not None:
