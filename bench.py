@@ -313,6 +313,13 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
                 draw(rr, colors, first + i, first + min(i + V, count))
         return step
 
+    # Part of setting up, like Renderer.init(): every context draws one full pass once, so that the working buffers of
+    # all its views exist (they are allocated at a context's first pass of that many views) whatever --warmup is; then
+    # the W warm-up steps.
+    if n_local >= V:
+        for rr, _, colors in lanes:
+            draw(rr, colors, 0, V)
+        torch.cuda.synchronize(dev)
     warm = make_step(0, args.warmup)
     for i in range(args.warmup):
         warm(i)
@@ -339,7 +346,7 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
         r.synchronize()
         return frames_, total_, span_
 
-    n_iso = max(V, min(args.steps, 20) // V * V)   # whole passes
+    n_iso = min(args.steps, max(V, min(args.steps, 20) // V * V))   # whole passes (a run of fewer steps than views has one shorter pass)
     iso_frames, iso_total, iso_span = isolated(n_iso, V)
     # the frame with nothing else in flight and no other context on the scene (config 2's "single frame"): the forks go first
     for rr, _, _ in lanes[1:]:
@@ -401,7 +408,7 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
             "config": {"workload": f"DamagedHelmet {W}x{H} single frame, {args.skybox_size}^2 skybox cube, irradiance 32^2, prefilter 128^2 x5, LUT 512^2, synthetic 4096x2048 HDR"
                                    + f"; step i renders frame i of a 1-degree-per-frame camera orbit that starts at the reference's default view, frame f on rank f mod {world}",
                        "covered_fraction": c, "triangles": tri_sum // max(n_cov, 1), "parallelism": "replicas only" if world == 1 else f"frame-sharded x{world}",
-                       "frames_in_flight_per_gpu": K * V, "passes_in_flight_per_gpu": K, "views_per_pass": V, "single_frame_ms": single_frame_ms,
+                       "frames_in_flight_per_gpu": K * V, "passes_in_flight_per_gpu": K, "views_per_pass": V, "untimed_setup_passes_per_context": 1 if n_local >= V else 0, "single_frame_ms": single_frame_ms,
                        "single_frame_mpix_per_s": npix / 1e6 / (single_frame_ms * 1e-3),
                        "covered_mpix_per_s_of_surface_kernel": V * c * npix / 1e6 / (iso_ms * 1e-3)},
             "kernel_ms": {"resolve_surface_fast_kernel": iso_ms, "resolve_surface_fast_kernel_in_flight": surf_ms, "resolve_surface_fast_kernel_lone_context": lone_ms,

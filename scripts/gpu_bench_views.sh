@@ -1,11 +1,11 @@
 #!/bin/bash
-# Frame time of the orbit for combinations of passes in flight and views per pass: scripts/gpu_bench_views.sh "K:V K:V ..."
+# Frame time of the orbit for combinations of passes in flight and views per pass: [BENCH_ARGS="--steps 20 --warmup 5"] scripts/gpu_bench_views.sh "K:V K:V ..."
 set -e
 mkdir -p gpurun_out
 list=${1:-"4:1 2:2 2:4 3:4 4:2 1:4 3:2"}
 for kv in $list; do
   k=${kv%%:*}; v=${kv##*:}
-  timeout -k 10 120 python bench.py --in-flight $k --views $v --no-cpu-baseline --no-prefilter > gpurun_out/bench_views_${k}_${v}.json 2> gpurun_out/bench_views_err.log
+  timeout -k 10 120 python bench.py --in-flight $k --views $v --no-cpu-baseline --no-prefilter $BENCH_ARGS > gpurun_out/bench_views_${k}_${v}.json 2> gpurun_out/bench_views_err.log
   python - $k $v <<'PY'
 import json, sys
 k, v = sys.argv[1:3]
