@@ -187,6 +187,11 @@ float prefilter_roughness(int level, int mips) { return mips > 1 ? (float)((doub
 constexpr uint64_t PREFILTER_TEXEL_OVERHEAD = 8;
 struct PrefilterCost { int kept[PBR_MAX_LEVELS]; uint64_t per_texel[PBR_MAX_LEVELS][6]; };
 void prefilter_costs(int mips, PrefilterCost* pc) {
+  // (the tables take a fraction of a millisecond of host arithmetic; a caller that filters map after map with one level
+  // count would otherwise pay it ahead of every call's first launch)
+  static thread_local int cached_mips = -1;
+  static thread_local PrefilterCost cached;
+  if (cached_mips == mips) { *pc = cached; return; }
   std::vector<PrefilterSample> table(PBR_PREFILTER_SAMPLES);
   for (int m = 0; m < mips; ++m) {
     float weight;
@@ -197,6 +202,7 @@ void prefilter_costs(int mips, PrefilterCost* pc) {
     const uint64_t pole = roughness == 0.0f ? 100 : roughness <= 0.17f ? 141 : roughness <= 0.28f ? 207 : 144;
     for (int f = 0; f < 6; ++f) pc->per_texel[m][f] = ((uint64_t)n + PREFILTER_TEXEL_OVERHEAD) * ((f == 2 || f == 3) ? pole : side);
   }
+  cached = *pc; cached_mips = mips;
 }
 
 // First texel (in the flattened (mip, face, y, x) order) of each of n shards of equal cost; cuts[n] = all texels.
