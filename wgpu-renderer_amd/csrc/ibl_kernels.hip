@@ -290,7 +290,8 @@ prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, i
   // Several samples at a time: the samples' source pixels are located first and their 12-byte loads issued together,
   // so that a wavefront has several times the requests in flight (the kernel's time is the latency of the requests that
   // leave L1, at full occupancy); the sums take the samples in their order.  2048^2 x 10 levels: 16.9 ms one sample at a
-  // time, 15.7 / 15.15 / 15.5 / 17.1 ms in groups of 2 / 3 / 4 / 6 (45 / 60 / 66 / 66 registers: beyond 64 a SIMD holds 7 waves).
+  // time, 15.7 / 15.15 / 15.5 / 17.1 ms in groups of 2 / 3 / 4 / 6 (45 / 60 / 66 / 66 registers: beyond 64 a SIMD holds 7 waves;
+  // groups of 4 and 5 held to 64 registers: 15.6 and 15.7 ms).
 #ifndef PBR_PREFILTER_GROUP
 #define PBR_PREFILTER_GROUP 3
 #endif
