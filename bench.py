@@ -121,6 +121,16 @@ def valu_issue(kernels, ms):
     return out
 
 
+def pass_of_step(i, count, views, contexts):
+    """What step i of `count` steps submits when frames are drawn `views` to a pass and the passes go to `contexts`
+    contexts in turn: (context, first frame, end frame) at every views-th step - the pass of that step's frames, the
+    last one shorter if `count` is not a multiple - and None at the steps between.  Every frame of the `count` steps is
+    drawn exactly once, in the region its step belongs to."""
+    if i % views:
+        return None
+    return (i // views) % contexts, i, min(i + views, count)
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -305,12 +315,12 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
             rr.draw_views_device(uniforms[lo:hi], [colors[v].data_ptr() for v in range(hi - lo)])
 
     def make_step(first, count):
-        """step i of `count` steps that start at frame `first`: with V frames per pass, every V-th step submits the pass
-        of its V frames (the last pass may be shorter), the steps between submit nothing"""
+        """step i of `count` steps that start at frame `first` (see pass_of_step)"""
         def step(i):
-            if i % V == 0:
-                rr, _, colors = lanes[(i // V) % K]
-                draw(rr, colors, first + i, first + min(i + V, count))
+            submit = pass_of_step(i, count, V, K)
+            if submit is not None:
+                lane, lo, hi = submit
+                draw(lanes[lane][0], lanes[lane][2], first + lo, first + hi)
         return step
 
     # Part of setting up, like Renderer.init(): every context draws one full pass once, so that the working buffers of

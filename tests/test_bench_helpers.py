@@ -95,3 +95,23 @@ def test_result_names_what_was_measured():
     a = b.parse_args([])                         # the committed table is that of the default run: whole passes
     frame, launch = b.measured_frame_traffic(a.views, a.in_flight), b.measured_traffic(b.surface_shape(a.in_flight, a.views))
     assert frame is not None and launch is not None and frame > launch / a.views   # a frame is more than its share of the surface launch
+
+
+def test_passes_cover_every_step_exactly_once():
+    """Whatever the step count, the views per pass and the contexts in flight: the passes submitted over the steps of a
+    region draw each of its frames once, none twice, none of another region; contexts take the passes in turn."""
+    b = _bench()
+    for count in (0, 1, 2, 5, 7, 20, 360, 361):
+        for views in (1, 2, 3, 4):
+            for contexts in (1, 3, 4):
+                drawn, lanes_used = [], []
+                for i in range(count):
+                    sub = b.pass_of_step(i, count, views, contexts)
+                    if sub is None:
+                        continue
+                    lane, lo, hi = sub
+                    assert lo == i and lo < hi <= count and hi - lo <= views and 0 <= lane < contexts
+                    drawn.extend(range(lo, hi))
+                    lanes_used.append(lane)
+                assert drawn == list(range(count)), (count, views, contexts)
+                assert lanes_used == [k % contexts for k in range(len(lanes_used))]
