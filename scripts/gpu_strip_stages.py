@@ -1,0 +1,29 @@
+"""Per-stage event times of the stress scene (10 x 10 helmets, 7680 x 4320): the whole frame and one of eight strips.
+python scripts/gpu_strip_stages.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+import bench
+pkg = entry.load_package()
+W, H = 7680, 4320
+g = pkg.glTFLoader(); g.load(pkg.renderer.DEFAULT_MODEL)
+models = bench.stress_instances(pkg, g.get_geometries()[0].model)
+r = pkg.Renderer(width=W, height=H, skybox_size=1024, instance_models=models)
+r.init()
+r.camera.update_camera_distance((5.0 - 30.0) * 100.0, 0.0)
+sharding = __import__("wgpu_renderer_amd.sharding", fromlist=["x"])
+import torch
+for name, (y0, y1) in (("whole frame", (0, H)), ("strip 3 of 8", sharding.strip_rows(H, 3, 8)), ("strip 0 of 8", sharding.strip_rows(H, 0, 8))):
+    out = torch.empty((y1 - y0, W, 4), dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    acc = {}
+    for i in range(6):
+        st = pkg._lib.FrameStats()
+        r.draw_frame_device(out.data_ptr(), y0=y0, y1=y1, stats=st)
+        if i >= 3:
+            for f, _ in st._fields_:
+                if f.startswith("ms_"):
+                    acc.setdefault(f, []).append(getattr(st, f))
+    print(name, {k: round(sum(v) / len(v) * 1000, 1) for k, v in acc.items()}, "us; set-up triangles", st.setup_triangles, flush=True)
+r.close()

@@ -567,7 +567,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   sky_b.sky = apr->sky_b.cube; sky_b.rgba8 = reinterpret_cast<uint32_t*>(color); sky_b.first = 0; sky_b.own_blocks = 0;
   sky_b.count = msaa ? n_tiles : std::min(n_tiles, std::max(0, (int)(n_tiles * share_setup)));
   const int sky_from_tile = sky_b.first + sky_b.count;
-  const VertexSource source = {nullptr, a->d_vsoa, a->d_inst_model, a->d_inst_normal};
+  const VertexSource source = {nullptr, a->d_vsoa, a->d_inst_model, a->d_inst_normal, {a->mesh_lo[0], a->mesh_lo[1], a->mesh_lo[2]}, {a->mesh_hi[0], a->mesh_hi[1], a->mesh_hi[2]}};
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[1], s));
   launch_setup_and_bin(s, dp, source, a->d_indices, fw.setup, fw.records, (uint32_t)fw.setup_cap, fw.tile_count, fw.bins, fw.overflow,
                        (uint32_t)fw.overflow_cap, counters, fw.live, a->n_indices / 3, a->n_instances, sky_b);
@@ -795,6 +795,13 @@ static int upload_mesh_common(PbrContext* c, const float* verts, int32_t n_verts
     HIP_TRY(c, hipMemcpy(c->d_inst_normal, instance_normal, bytes, hipMemcpyHostToDevice));
   }
   c->n_verts = n_verts; c->n_indices = n_indices; c->n_instances = instance_count;
+  for (int k = 0; k < 3; ++k) { c->mesh_lo[k] = verts[k]; c->mesh_hi[k] = verts[k]; }
+  for (int32_t i = 1; i < n_verts; ++i)
+    for (int k = 0; k < 3; ++k) {
+      const float v = verts[8 * (size_t)i + k];
+      if (!(v >= c->mesh_lo[k])) c->mesh_lo[k] = v;   // (a NaN coordinate ends up in both bounds, and the box then culls nothing)
+      if (!(v <= c->mesh_hi[k])) c->mesh_hi[k] = v;
+    }
   return PBR_OK;
 }
 
@@ -1210,6 +1217,7 @@ int pbr_draw_views_device(PbrContext* c, int32_t n_views, const PbrFrameUniforms
     bt.setup = w->d_setup; bt.setup_cap = (uint32_t)w->setup_cap; bt.tile_count = w->d_tile_count; bt.bins = w->d_bins; bt.overflow = w->d_overflow;
     bt.overflow_cap = (uint32_t)w->overflow_cap; bt.counters = counters; bt.live = live; bt.records = w->d_records;
     bt.vsoa = a->d_vsoa; bt.inst_model = a->d_inst_model; bt.inst_normal = a->d_inst_normal;
+    for (int k = 0; k < 3; ++k) { bt.mesh_lo[k] = a->mesh_lo[k]; bt.mesh_hi[k] = a->mesh_hi[k]; }
     RasterTargets& ra = va.ra;
     ra.setup = w->d_setup; ra.tile_count = w->d_tile_count; ra.bins = w->d_bins; ra.overflow = w->d_overflow; ra.overflow_cap = (uint32_t)w->overflow_cap;
     ra.counters = counters; ra.next_counters = next_counters; ra.lists = w->quad_lists; ra.rgba8 = static_cast<uint32_t*>(d_rgba8[v]); ra.live = live;

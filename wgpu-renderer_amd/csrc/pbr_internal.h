@@ -130,6 +130,7 @@ struct PbrContext {
   float* d_inst_normal = nullptr;
   int32_t n_verts = 0, n_indices = 0, n_instances = 0;
   bool has_instance_mats = false;
+  float mesh_lo[3] = {1.0f, 1.0f, 1.0f}, mesh_hi[3] = {0.0f, 0.0f, 0.0f};   // bounding box of the positions (lo > hi: no mesh)
 
   // material textures
   uint32_t* d_tex[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -190,7 +191,7 @@ void launch_vertex_stage(hipStream_t s, const FrameParams& p, const float* vsoa,
                          VertexOut* out, int n_verts, int n_instances, const SkyShare& share);
 // where the setup kernel takes a triangle's vertices from: transformed vertices in memory (vout), or the
 // vertex streams, transformed on the fly (vsoa set, vout unused)
-struct VertexSource { const VertexOut* vout; const float* vsoa; const float* inst_model; const float* inst_normal; };
+struct VertexSource { const VertexOut* vout; const float* vsoa; const float* inst_model; const float* inst_normal; float mesh_lo[3], mesh_hi[3]; };   // (the box: see BinTargets)
 // The fullest tiles (more than PBR_DENSE_TILE_REFS triangle references), listed by the set-up launch as each crosses
 // that mark, so that the rasteriser can start them before anything else - the frame waits for the fullest tile:
 // tiles[k] = serial << 24 | tile for the k-th tile to cross it (k from frame counter 4, k < cap); info[tile] =
@@ -210,6 +211,9 @@ struct BinTargets {
   TriRecord* records;
   // when vsoa is set the triangle's vertices are transformed here from the vertex streams (and vout is not read)
   const float* vsoa; const float* inst_model; const float* inst_normal;
+  // bounding box of the mesh's positions in object space (lo > hi: none known): an instance whose box misses the
+  // frame's rows or columns is skipped as a whole, before any of its triangles is fetched
+  float mesh_lo[3], mesh_hi[3];
 };
 void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSource& src, const uint32_t* indices, SetupTri* setup, TriRecord* records,
                           uint32_t setup_cap, uint32_t* tile_count, uint32_t* bins, uint2* overflow, uint32_t overflow_cap, uint32_t* counters,

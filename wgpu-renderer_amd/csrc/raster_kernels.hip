@@ -321,6 +321,35 @@ PBR_DEV void fetch_triangle(const FrameParams* p, const VertexOut* vout, const u
   }
 }
 
+// Whether instance `inst` lies wholly above, below, left or right of the frame's rows and columns: the eight corners
+// of the mesh's bounding box go through the instance's transform (lanes 0 - 7 of every group of eight take one each,
+// three butterfly steps give every lane the extremes); with every corner in front of the eye their screen positions
+// bound those of all the instance's vertices.  Two pixels of margin stand for the rounding of this arithmetic against
+// the vertex stage's: the test only ever skips work whose triangles the row and column test of their own bounding
+// boxes would reject.  (For a rank that draws one strip of a large instanced scene this is most of the scene.)
+PBR_DEV bool instance_misses_frame(const FrameParams* __restrict__ p, const BinTargets& bt, int inst) {
+  if (!(bt.mesh_lo[0] <= bt.mesh_hi[0])) return false;   // no box known
+  const int c = threadIdx.x & 7;
+  const float x = (c & 1) ? bt.mesh_hi[0] : bt.mesh_lo[0], y = (c & 2) ? bt.mesh_hi[1] : bt.mesh_lo[1], z = (c & 4) ? bt.mesh_hi[2] : bt.mesh_lo[2];
+  const float* m = p->has_instance_mats ? bt.inst_model + 16 * inst : p->u.model;
+  const float wx = m[0] * x + m[4] * y + m[8] * z + m[12], wy = m[1] * x + m[5] * y + m[9] * z + m[13], wz = m[2] * x + m[6] * y + m[10] * z + m[14],
+              ww = m[3] * x + m[7] * y + m[11] * z + m[15];
+  const float* pv = p->pv;
+  const float cx = pv[0] * wx + pv[4] * wy + pv[8] * wz + pv[12] * ww, cy = pv[1] * wx + pv[5] * wy + pv[9] * wz + pv[13] * ww,
+              cw = pv[3] * wx + pv[7] * wy + pv[11] * wz + pv[15] * ww;
+  const bool in_front = cw > 1e-6f;
+  if (__ballot(!in_front) != 0ull) return false;   // a corner at or behind the eye (or a NaN): its screen position bounds nothing
+  float sx = (cx / cw + 1.0f) * 0.5f * (float)p->W, sy = (1.0f - cy / cw) * 0.5f * (float)p->H;
+  float xmin = sx, xmax = sx, ymin = sy, ymax = sy;
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+    ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+  }
+  const float margin = 2.0f;
+  return ymax < (float)p->y0 - margin || ymin > (float)p->y1 + margin || xmax < -margin || xmin > (float)p->W + margin;
+}
+
 // One triangle per thread: trivial rejection, the shading record, and the triangle set up for the rasteriser in
 // `pending` (left empty when it is culled).  Returns true for a triangle that crosses a clip plane: its thread clips
 // it afterwards (clip_one), away from the common path, whose wavefronts then never wait for what only the clipping
@@ -392,6 +421,7 @@ __global__ void __launch_bounds__(256) setup_kernel(const FrameParams frame_para
   if ((int)blockIdx.x >= share.own_blocks) { sky_tile(p, share.sky, share.rgba8, share.first + (int)blockIdx.x - share.own_blocks); SETUP_TRACE(4); return; }
   const int inst = (int)blockIdx.x / blocks_per_instance;
   const int t = ((int)blockIdx.x - inst * blocks_per_instance) * 256 + threadIdx.x;
+  if (instance_misses_frame(p, bt, inst)) return;   // (the same answer in every wavefront of the workgroup)
   __shared__ BinWindow s_window[4];
   Pending pending;
   pending.n_tiles = 0;
@@ -415,6 +445,7 @@ setup_views_kernel(const SetupViews sv, const VertexOut* __restrict__ vout, cons
   const BinTargets& bt = sv.bt[blockIdx.y];
   const int inst = (int)blockIdx.x / blocks_per_instance;
   const int t = ((int)blockIdx.x - inst * blocks_per_instance) * 256 + threadIdx.x;
+  if (instance_misses_frame(p, bt, inst)) return;
   __shared__ BinWindow s_window[4];
   Pending pending;
   pending.n_tiles = 0;
@@ -947,6 +978,7 @@ void launch_setup_and_bin(hipStream_t s, const FrameParams& p, const VertexSourc
   bt.setup = setup; bt.setup_cap = setup_cap; bt.tile_count = tile_count; bt.bins = bins; bt.overflow = overflow; bt.overflow_cap = overflow_cap;
   bt.counters = counters; bt.live = live; bt.records = records;
   bt.vsoa = src.vsoa; bt.inst_model = src.inst_model; bt.inst_normal = src.inst_normal;
+  for (int k = 0; k < 3; ++k) { bt.mesh_lo[k] = src.mesh_lo[k]; bt.mesh_hi[k] = src.mesh_hi[k]; }
   const int per_instance = (n_tris + 255) / 256;
   SkyShare share = share_in;
   share.own_blocks = per_instance * n_instances;
