@@ -535,6 +535,32 @@ def test_instanced_grid_matches_oracle():
         s.renderer.close()
 
 
+def test_instances_outside_the_frame_are_skipped_without_a_trace():
+    """Helmets wholly left of, right of, above and below the frame, one straddling its right edge, one straddling its
+    top edge, one behind the camera and one in the middle: the set-up launch skips whole instances whose bounding box
+    misses the frame, and the visibility buffer must still be the oracle's, bit for bit - in the whole frame and in
+    row bands, for which instances above or below the band are skipped as well."""
+    pkg = pu._pkg()
+    g = pkg.glTFLoader(); g.load(pkg.renderer.DEFAULT_MODEL)
+    base = g.get_geometries()[0].model
+    offsets = [(0.0, 0.0, 0.0), (-9.0, 0.0, 0.0), (9.0, 0.0, 0.0), (0.0, 6.0, 0.0), (0.0, -6.0, 0.0), (3.4, 0.5, 0.0), (-0.8, 2.0, 0.0), (0.0, 0.0, 9.0)]
+    models = np.stack([pkg.mathx.mul(pkg.mathx.translate(pkg.mathx.identity(), list(o)), base) for o in offsets])
+    s = pu.SmallScene.build(width=320, height=180, instance_models=models)
+    r = s.renderer
+    try:
+        rgba, vis = s.render_gpu()
+        orgba, ovis, margin = s.render_oracle_with_margins()
+        assert (vis == ovis).all()
+        seen = set(np.unique((vis[vis > 0] - 1) // 15452).tolist())
+        assert seen == {0, 5, 6}, seen                               # the middle one and the two that straddle an edge
+        assert_frame_close(rgba, orgba, vis, ovis, "instances outside the frame", margin)
+        for y0, y1 in ((0, 60), (60, 120), (120, 180), (2, 4)):
+            band, bvis = r.draw_frame(y0=y0, y1=y1, want_vis=True)
+            assert (bvis == vis[y0:y1]).all() and (band == rgba[y0:y1]).all(), (y0, y1)
+    finally:
+        r.close()
+
+
 def test_working_buffer_overflow_is_noticed_and_repaired():
     """A camera inside a 3 x 3 grid of helmets (triangles cut by the near plane leave several pieces each), with the
     set-up buffer and the tile-reference list forced far too small: the synchronous entry point enlarges them and
