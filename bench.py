@@ -416,7 +416,8 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"DamagedHelmet {W}x{H} single frame, {args.skybox_size}^2 skybox cube, irradiance 32^2, prefilter 128^2 x5, LUT 512^2, synthetic 4096x2048 HDR"
-                                   + f"; step i renders frame i of a 1-degree-per-frame camera orbit that starts at the reference's default view, frame f on rank f mod {world}",
+                                   + f"; step i renders frame i of a 1-degree-per-frame camera orbit that starts at the reference's default view, frame f on rank f mod {world}"
+                                   + (f"; a rank's frames are submitted {V} consecutive ones per call (pbr_draw_views_device), {K} calls in flight" if V > 1 else ""),
                        "covered_fraction": c, "triangles": tri_sum // max(n_cov, 1), "parallelism": "replicas only" if world == 1 else f"frame-sharded x{world}",
                        "frames_in_flight_per_gpu": K * V, "passes_in_flight_per_gpu": K, "views_per_pass": V, "untimed_setup_passes_per_context": 1 if n_local >= V else 0, "single_frame_ms": single_frame_ms,
                        "single_frame_mpix_per_s": npix / 1e6 / (single_frame_ms * 1e-3),
