@@ -519,18 +519,27 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
     texels = sum(level_texels)
     info = {"config": f"{size}^2 cube, {mips} mips, 1024 samples/texel", "n_gpus": world}
     try:
+        how = os.environ.get("PBR_PREFILTER_EXCHANGE", "collective")
+        sent = [0]
+
         def once():
             if not use_dist:
                 pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, size, mips, 1024, 0, 1))
             else:
-                parallel.prefilter_sharded(r, size, mips, rank, world, dev)
+                sent[0] = parallel.prefilter_sharded(r, size, mips, rank, world, dev, how=how)
             torch.cuda.synchronize(dev)
-        once()                                   # allocate + warm
+        once()                                   # allocate + warm (the exchange's staging buffers too: they are kept)
         ms = timed_region(torch, dist, use_dist, dev, 1, lambda i: once()) * 1e3
         if use_dist:
-            info["exchange"] = f"all-gather of the {texels * 16 / 1e6:.0f} MB map included"
             cuts = sharding.prefilter_cuts(size, mips, world)
             info["shard_texels"] = [b - a for a, b in zip(cuts, cuts[1:])]
+            info["replicated_texels"] = cuts[0]
+            info["exchange_bytes_per_rank"] = sharding.prefilter_exchange_bytes(size, mips, world, how)
+            info["exchange_bytes_rank0_sent"] = sent[0]
+            info["exchange"] = (f"every rank filters the first {cuts[0]} texels (roughness 0) for itself; the other {(texels - cuts[0]) * 16 / 1e6:.0f} MB of the "
+                                f"{texels * 16 / 1e6:.0f} MB map are cut by cost and exchanged ("
+                                + ("one all-gather of equal chunks, staging kept between calls" if how != "p2p" else "peer to peer, in place")
+                                + "), included in ms")
         kept = sharding.prefilter_kept_samples(mips)
         executed = sum(k * t for k, t in zip(kept, level_texels))
         info.update({"ms": ms,

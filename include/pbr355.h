@@ -120,10 +120,11 @@ int pbr_upload_hdr(PbrContext* ctx, const float* rgba32f, int32_t w, int32_t h);
 int pbr_ibl_equirect_to_cube(PbrContext* ctx, int32_t size);   /* CubemapType.SKYBOX, equirectangular.wgsl */
 int pbr_ibl_irradiance(PbrContext* ctx, int32_t size);         /* CubemapType.IRRADIANCE, irradiancemap.wgsl */
 /* CubemapType.PREFILTER, prefiltermap.wgsl: mips levels with roughness mip/(mips-1) (renderer.ts:1559),
- * samples must be 1024 (SAMPLE_COUNT, prefiltermap.wgsl:3).  The texels of all mips, flattened in
- * (mip, face, y, x) order, are cut into shard_count ranges of equal cost (pbr_ibl_prefilter_partition)
- * and only range shard_index is computed; (0,1) computes everything.  A texel's value does not depend
- * on the shard that computes it. */
+ * samples must be 1024 (SAMPLE_COUNT, prefiltermap.wgsl:3).  (0,1) computes everything.  With shard_count > 1 the
+ * call filters what shard shard_index needs to hold and to contribute (pbr_ibl_prefilter_partition): the leading
+ * levels that are cheaper to filter than to send (roughness 0: one sample per texel), whole, and the shard's own
+ * range of the remaining texels, which are cut into shard_count ranges of equal cost in the flattened
+ * (mip, face, y, x) order.  A texel's value does not depend on the shard that computes it. */
 int pbr_ibl_prefilter(PbrContext* ctx, int32_t size, int32_t mips, int32_t samples, int32_t shard_index, int32_t shard_count);
 /* The same filter for an arbitrary piece of the map: texels [first_texel, first_texel + texel_count) of the
  * flattened (mip, face, y, x) order (the dispatch loop of renderer.ts:1558-1609 cut at any texel).  For drivers
@@ -141,16 +142,20 @@ int pbr_ibl_download(PbrContext* ctx, int which, int32_t level, void* out, size_
  * a derived copy that it rebuilds at the first frame after this call: call it (again) after the
  * last write through the pointer, and order that write before the frame. */
 int pbr_ibl_device_ptr(PbrContext* ctx, int which, void** dev_ptr, size_t* total_bytes);
-/* Byte range [begin,end) of the prefilter map that shard (shard_index, shard_count) writes. */
+/* Byte range [begin,end) of the prefilter map that only shard (shard_index, shard_count) computes: what it has to
+ * send to the others (the leading levels that every shard filters for itself lie in front of shard 0's range). */
 int pbr_ibl_prefilter_shard_range(PbrContext* ctx, int32_t shard_index, int32_t shard_count, size_t* begin, size_t* end);
-/* How the per-level loop of generateCubemap (renderer.ts:1558-1609, roughness schedule :1559) is cut into
- * shard_count pieces of equal cost: cuts[k] is the first texel of shard k in the flattened (mip, face, y, x)
- * order and cuts[shard_count] the texel count of the whole map (shard_count + 1 entries).  A texel of level m
- * weighs the number of the 1024 GGX samples that contribute at that level's roughness (those with N.L > 0,
- * prefiltermap.wgsl:138; roughness 0 needs a single one) plus a small constant for the per-texel work, so level 0,
- * three quarters of the texels and almost none of the work, does not fill most shards; a sample of the +-Y faces and
- * of the rougher levels weighs more by factors measured on MI355X (its source pixels are scattered over more cache
- * lines).  Host arithmetic only: needs neither a context nor a device. */
+/* How the per-level loop of generateCubemap (renderer.ts:1558-1609, roughness schedule :1559) is divided among
+ * shard_count shards (shard_count + 1 entries).  cuts[0] is the number of texels, at the front of the flattened
+ * (mip, face, y, x) order, that every shard filters for itself and nobody sends: the leading levels whose texels
+ * keep at most eight of the 1024 GGX samples, i.e. roughness 0, where a texel is one sample and a GPU produces
+ * texels faster than its links carry them (level 0: three quarters of the map's bytes, a fiftieth of its work);
+ * 0 for a single shard.  Shard k owns texels [cuts[k], cuts[k + 1]), cuts[shard_count] being the texel count of
+ * the whole map; the ranges have equal cost.  A texel of level m weighs the number of the 1024 GGX samples that
+ * contribute at that level's roughness (those with N.L > 0, prefiltermap.wgsl:138) plus a small constant for the
+ * per-texel work; a sample of the +-Y faces and of the rougher levels weighs more by factors measured on MI355X
+ * (its source pixels are scattered over more cache lines).  Host arithmetic only: needs neither a context nor a
+ * device. */
 int pbr_ibl_prefilter_partition(int32_t size, int32_t mips, int32_t shard_count, uint64_t* cuts);
 /* Number of the 1024 samples of prefiltermap.wgsl:131-168 that contribute (N.L > 0) at level `level` of `mips`
  * levels: the executed work per texel, for cost models and benchmarks.  Host arithmetic only. */
@@ -184,13 +189,18 @@ int pbr_draw_frame_device(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w,
  * per frame.  Queues the pass and returns; overflow reporting as for pbr_draw_frame_device without stats.  Views with
  * another sampler than the reference's default (index 15), multisampled views, or textures of differing sizes are
  * drawn one after the other instead.  The context keeps working buffers per view (some 70 MB per further view at
- * 3840 x 2160) until it is destroyed. */
+ * 3840 x 2160) until it is destroyed or pbr_release_view_buffers is called. */
 int pbr_draw_views_device(PbrContext* ctx, int32_t n_views, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1,
                           void* const* d_rgba8);
+/* Gives back the working buffers pbr_draw_views_device keeps for views 1, 2, ... of its passes (view 0 works in
+ * the context's own): waits for the context's stream, then frees them.  A later pass allocates them again.  For
+ * callers that drew a camera path in passes and go on frame by frame (the reference holds no such memory: it draws
+ * one frame per submit, renderer.ts:2033). */
+int pbr_release_view_buffers(PbrContext* ctx);
 /* pbr_draw_frame_device for callers that cannot allocate device memory: code under HIP graph capture, serving
  * loops that must not touch the allocator, harnesses that forbid hipMalloc.  It has no counterpart in the
  * reference.  Same pass, same result bits, but everything the frame keeps between its launches (append counters,
- * tile bins, set-up triangles, shading records, quad work lists) lives in one fixed array of about 26 MB that
+ * tile bins, set-up triangles, shading records, quad work lists) lives in one fixed array of 26.5 MB that
  * every GPU the library runs on holds until the process ends, so the call makes no hipMalloc / hipFree and the
  * frame has to fit it: single-sample pipeline only (PBR_E_UNSUPPORTED with bit 16 of sampler_index), at most
  * 2048 tiles of 32 x 32 pixels in rows [y0,y1) (e.g. 1920 x 1080) and at most 32768 triangles over all instances

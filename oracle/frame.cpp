@@ -264,6 +264,14 @@ V4 cube_sample_level(const CubeTex& t, int level, const CubeCoord& c) {
 // lambda of an implicit-LOD cube lookup of direction r with quad differences drdx, drdy.
 float cube_lambda(int size, V3 r, V3 drdx, V3 drdy) {
   CubeCoord c = cube_select(r);
+  {
+    // (test instrumentation, see note_margin) the face is a discrete decision, and the derivatives are projected through
+    // the chosen face's table: across a face edge the level of detail jumps.  Margin = how far the two largest components
+    // of the direction are apart, relative to the larger.
+    float a[3] = {std::fabs(r.x), std::fabs(r.y), std::fabs(r.z)};
+    std::sort(a, a + 3);
+    if (a[2] > 0.0f) note_margin((a[2] - a[1]) / a[2]);
+  }
   float ma = std::fabs(c.rc), sgn = c.rc >= 0 ? 1.0f : -1.0f;
   float rho[2];
   const V3 d[2] = {drdx, drdy};

@@ -194,7 +194,8 @@ def test_sharding_partitions(pkg):
         total = sh.prefilter_total_texels(2048, 10)
         assert total == sum(6 * (2048 >> m) ** 2 for m in range(10)) == 33554400 + 0 * world
         ranges = [sh.prefilter_shard_texels(2048, 10, r, world) for r in range(world)]
-        assert ranges[0][0] == 0 and ranges[-1][1] == total
+        # level 0 (roughness 0, one sample per texel) is filtered by every rank of several and belongs to no shard
+        assert ranges[0][0] == sh.prefilter_replicated_texels(2048, 10, world) == (0 if world == 1 else 6 * 2048 ** 2) and ranges[-1][1] == total
         assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
         for height in (4320, 2160, 721, 2):
             rows = [sh.strip_rows(height, r, world) for r in range(world)]
@@ -246,9 +247,10 @@ def test_prefilter_shards_carry_equal_cost(pkg):
     def load(b, e, column):
         return sum(max(0, min(e, f + n) - max(b, f)) * seg[column] for seg in segments for f, n in [seg[:2]])
 
+    level0 = 6 * size * size
     for world in (2, 4, 8, 3, 7):
         cuts = sh.prefilter_cuts(size, mips, world)
-        assert cuts[0] == 0 and cuts[-1] == total_texels and all(a < b for a, b in zip(cuts, cuts[1:]))
+        assert cuts[0] == level0 and cuts[-1] == total_texels and all(a < b for a, b in zip(cuts, cuts[1:]))
         costs = [load(b, e, 2) for b, e in zip(cuts, cuts[1:])]
         assert max(costs) / (sum(costs) / world) <= 1.02, (world, costs)
         samples = [load(b, e, 3) for b, e in zip(cuts, cuts[1:])]          # without the measured factors: still no idle shard
@@ -257,9 +259,30 @@ def test_prefilter_shards_carry_equal_cost(pkg):
     # the reference's own size: five levels of 128^2
     for world in (2, 4, 8):
         cuts = sh.prefilter_cuts(128, 5, world)
-        assert cuts[0] == 0 and cuts[-1] == sh.prefilter_total_texels(128, 5) and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        assert cuts[0] == 6 * 128 * 128 and cuts[-1] == sh.prefilter_total_texels(128, 5) and all(a <= b for a, b in zip(cuts, cuts[1:]))
     assert sh.prefilter_cuts(128, 5, 1) == [0, sh.prefilter_total_texels(128, 5)]
-    assert sh.prefilter_cuts(16, 1, 4) == [0, 384, 768, 1152, 1536]      # a single level (roughness 0): equal texel counts
+    assert sh.prefilter_cuts(16, 1, 4) == [1536] * 5      # a single level (roughness 0): every rank filters it, nothing is sent
+
+
+def test_prefilter_exchange_carries_only_what_is_worth_sending(pkg):
+    """Equal cost is not equal bytes: level 0 is 403 MB of the 2048^2 x 10 map's 537 MB and 0.3 ms of its 15 ms on one
+    GPU, so it must not cross a link.  What a rank contributes to the exchange, for both ways of exchanging: at most
+    25 MB at eight ranks (and in proportion at fewer), at most 1.3 times the mean range, the chunks of the
+    equal-chunk all-gather included; everything a rank does not receive it filters itself."""
+    sh = __import__("wgpu_renderer_amd.sharding", fromlist=["x"])
+    size, mips = 2048, 10
+    total = sh.prefilter_total_texels(size, mips)
+    for world in (2, 4, 8):
+        cuts = sh.prefilter_cuts(size, mips, world)
+        own = [16 * (e - b) for b, e in zip(cuts, cuts[1:])]
+        assert sum(own) == 16 * (total - 6 * size * size) == 134_217_216
+        for how in ("collective", "p2p"):
+            sent = sh.prefilter_exchange_bytes(size, mips, world, how)
+            assert len(sent) == world and all(s >= o for s, o in zip(sent, own))
+            assert max(sent) <= 25e6 * 8 / world, (world, how, sent)
+            assert max(sent) / (sum(own) / world) <= 1.3, (world, how, sent)
+        assert sh.prefilter_exchange_bytes(size, mips, world, "p2p") == own
+    assert sh.prefilter_exchange_bytes(size, mips, 1) == [16 * total]
 
 
 def test_gltf_loader_without_reference_limits(tmp_path, pkg):

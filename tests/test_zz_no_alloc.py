@@ -40,7 +40,11 @@ def test_static_frame_equals_device_frame():
         assert static_entry(r._ctx, C.byref(u), 640, 360, 0, 360, C.c_void_p(probe.data_ptr())) == lib.PBR_E_STATE
         assert b"pbr_draw_frame_device" in r._lib.pbr_last_error(r._ctx)
 
+        free_before_first_frame = torch.cuda.mem_get_info()[0]
         want_big = _draw(scene, device_entry, 640, 360)
+        # (the ordinary entry point's first frame allocates its working buffers and the lookup copies: the measurement
+        # below does see allocations of this kind)
+        assert torch.cuda.mem_get_info()[0] < free_before_first_frame
         got_big = _draw(scene, static_entry, 640, 360)                 # first call
         assert (got_big == want_big).all() and (got_big[..., 3] == 255).all()
         r.camera.update_camera_rotation(-300.0, 120.0)                 # another view, and a smaller target: fewer tiles, shorter lists
@@ -53,6 +57,18 @@ def test_static_frame_equals_device_frame():
         assert (band == want_small[32:96]).all()
         r.camera = scene.pkg.Camera()
         assert (_draw(scene, static_entry, 640, 360) == want_big).all()
+        # the property the entry point is named for: the device's free memory is the same before and after its calls
+        # (targets allocated beforehand, both target sizes and a band, nothing else running on the device)
+        targets = {(w, h): torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda:0") for w, h in ((640, 360), (250, 130))}
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        for (w, h, y0, y1) in ((640, 360, 0, 360), (250, 130, 0, 130), (250, 130, 32, 96), (640, 360, 0, 360)):
+            r.width, r.height = w, h
+            uu = r.frame_uniforms()
+            lib.check(r._ctx, static_entry(r._ctx, C.byref(uu), w, h, y0, y1, C.c_void_p(targets[(w, h)].data_ptr())))
+        r.synchronize()
+        assert torch.cuda.mem_get_info()[0] == free0
+        assert (targets[(640, 360)].cpu().numpy() == want_big).all()
         # the ordinary entry point still works afterwards and agrees
         assert (_draw(scene, device_entry, 640, 360) == want_big).all()
 

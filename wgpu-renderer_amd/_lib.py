@@ -58,6 +58,7 @@ EXPORTS = {
     "pbr_draw_frame": (C.c_int, [C.c_void_p, C.POINTER(FrameUniforms), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
     "pbr_draw_frame_device": (C.c_int, [C.c_void_p, C.POINTER(FrameUniforms), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(FrameStats)]),
     "pbr_draw_views_device": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(FrameUniforms), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pbr_release_view_buffers": (C.c_int, [C.c_void_p]),
     "pbr_draw_frame_static": (C.c_int, [C.c_void_p, C.POINTER(FrameUniforms), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "pbr_debug_vertex_stage": (C.c_int, [C.c_void_p, C.POINTER(FrameUniforms), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pbr_debug_texture_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

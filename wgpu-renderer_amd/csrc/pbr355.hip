@@ -32,7 +32,7 @@ constexpr size_t kRecords = align_up(kOverflow + kOverflowCap * sizeof(uint2));
 constexpr size_t kUniform = align_up(kRecords + (size_t)PBR_STATIC_MAX_TRIANGLES * sizeof(TriRecord));
 constexpr size_t kMixedPos = align_up(kUniform + kQuads * sizeof(uint2));
 constexpr size_t kMixedIds = align_up(kMixedPos + kQuads * sizeof(uint32_t));
-constexpr size_t kBytes = align_up(kMixedIds + kQuads * sizeof(uint4));                           // about 24 MB
+constexpr size_t kBytes = align_up(kMixedIds + kQuads * sizeof(uint4));                           // 26.5 MB
 }  // namespace static_layout
 static __device__ __align__(256) unsigned char scratch[static_layout::kBytes];
 
@@ -205,24 +205,41 @@ void prefilter_costs(int mips, PrefilterCost* pc) {
   cached = *pc; cached_mips = mips;
 }
 
-// First texel (in the flattened (mip, face, y, x) order) of each of n shards of equal cost; cuts[n] = all texels.
+// A level whose texels take less time to filter than to send is not worth sharding: every shard filters it for itself
+// and it never crosses a link.  At roughness 0 a texel is one sample (a copy of its source pixel): one MI355X writes
+// 90 G such texels a second (2048^2 x 6 in 0.28 ms), 1.4 TB/s of output, more than its seven xGMI links carry
+// together, while a texel of 1000 samples is produced at 9 GB/s.  The break-even lies near ten samples per texel; of
+// the reference's roughness schedule (renderer.ts:1559) only roughness 0, i.e. level 0, is below it.
+constexpr int PREFILTER_REPLICATE_MAX_SAMPLES = 8;
+int prefilter_first_sharded_level(const PrefilterCost& pc, int mips, int n) {
+  if (n <= 1) return 0;
+  int first = 0;
+  while (first < mips && pc.kept[first] <= PREFILTER_REPLICATE_MAX_SAMPLES) ++first;
+  return first;
+}
+
+// How n shards divide the map.  cuts[0] texels at the front of the flattened (mip, face, y, x) order - the levels
+// every shard filters for itself, see above; 0 for a single shard - belong to no shard; shard k owns texels
+// [cuts[k], cuts[k + 1]), ranges of equal cost; cuts[n] = all texels.
 // The reference filters level after level (renderer.ts:1558-1609); level 0 holds three quarters of the texels
 // but, at roughness 0, almost none of the work, so equal texel counts would leave most shards idle.
 void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
   PrefilterCost pc;
   prefilter_costs(mips, &pc);
-  uint64_t total_cost = 0, total_texels = 0;
+  const int first_level = prefilter_first_sharded_level(pc, mips, n);
+  uint64_t total_cost = 0, total_texels = 0, replicated_texels = 0;
   for (int m = 0; m < mips; ++m) {
     const uint64_t s = (uint64_t)std::max(1, size >> m);
-    for (int f = 0; f < 6; ++f) total_cost += s * s * pc.per_texel[m][f];
+    if (m < first_level) replicated_texels += 6 * s * s;
+    else for (int f = 0; f < 6; ++f) total_cost += s * s * pc.per_texel[m][f];
     total_texels += 6 * s * s;
   }
-  cuts[0] = 0; cuts[n] = total_texels;
+  cuts[0] = replicated_texels; cuts[n] = total_texels;
   for (int k = 1; k < n; ++k) {
     const uint64_t target = (uint64_t)(((unsigned __int128)total_cost * (unsigned)k) / (unsigned)n);
-    uint64_t before_cost = 0, before_texels = 0;
+    uint64_t before_cost = 0, before_texels = replicated_texels;
     bool placed = false;
-    for (int m = 0; m < mips && !placed; ++m) {
+    for (int m = first_level; m < mips && !placed; ++m) {
       const uint64_t s = (uint64_t)std::max(1, size >> m), face_texels = s * s;
       for (int f = 0; f < 6 && !placed; ++f) {
         const uint64_t c = face_texels * pc.per_texel[m][f];
@@ -332,6 +349,9 @@ struct PbrContextPrivate {
   Bordered sky_b, irr_b, pre_b;
   uint4* d_lut_quad = nullptr; int lut_quad_size = 0; bool lut_quad_dirty = true;   // footprint copy of the BRDF table for the resolve (ResolveInputs::lut_quad)
   uint4* d_atlas = nullptr; size_t atlas_texels = 0; bool atlas_dirty = true;       // interleaved copy of five equally sized material textures (ResolveInputs::atlas)
+  // Rebuilds of the lookup copies above are queued on the owner's stream without waiting; this event marks the end of the
+  // last one, and every frame drawn on another stream (a fork's, or a stream set later) waits for it first.
+  hipEvent_t copies_ready = nullptr; hipStream_t copies_stream = nullptr; bool copies_pending = false;
   int surface_blocks = 0;                 // resident workgroups of the surface kernel on this device
   int counter_set = 0;                    // which of the two sets of append counters the next frame uses
   bool used_static = false;               // pbr_draw_frame_static has run: its overflow flag lives in the device's fixed array
@@ -386,8 +406,9 @@ static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const
 }
 
 // The lookup copies derived from the IBL maps and material textures (bordered cubes, BRDF footprint table, interleaved
-// textures) belong to the scene's owner and are rebuilt on its stream; a forked context that finds them stale waits for
-// that stream before its own launches read them.
+// textures) belong to the scene's owner and are rebuilt on its stream, whoever finds them stale; the rebuild is only
+// queued.  Frames on the owner's stream follow it in stream order; frames on any other stream (the forks') wait for the
+// event recorded behind it (wait_for_lookup_copies), whether they triggered the rebuild or the owner's own first frame did.
 static int refresh_lookup_copies(PbrContext* c, PbrContext* a, PbrContextPrivate* apr, bool one_size) {
   int rc = PBR_OK;
   if ((rc = refresh_bordered(a, apr->sky_b, a->sky)) || (rc = refresh_bordered(a, apr->irr_b, a->irr)) || (rc = refresh_bordered(a, apr->pre_b, a->pre))) return rc;
@@ -416,7 +437,19 @@ static int refresh_lookup_copies(PbrContext* c, PbrContext* a, PbrContextPrivate
     launch_material_atlas(a->stream, chains, apr->d_atlas, texels);
     apr->atlas_dirty = false;
   }
-  if (a != c) HIP_TRY(c, hipStreamSynchronize(a->stream));
+  if (!apr->copies_ready) HIP_TRY(c, hipEventCreateWithFlags(&apr->copies_ready, hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(apr->copies_ready, a->stream));
+  apr->copies_stream = a->stream; apr->copies_pending = true;
+  return PBR_OK;
+}
+
+// Orders this context's next launches behind the last rebuild of the lookup copies when that ran on another stream.
+static int wait_for_lookup_copies(PbrContext* c, PbrContextPrivate* apr) {
+  if (!apr->copies_pending || c->stream == apr->copies_stream) return PBR_OK;
+  const hipError_t q = hipEventQuery(apr->copies_ready);
+  if (q == hipSuccess) { apr->copies_pending = false; return PBR_OK; }
+  if (q != hipErrorNotReady) HIP_TRY(c, q);
+  HIP_TRY(c, hipStreamWaitEvent(c->stream, apr->copies_ready, 0));
   return PBR_OK;
 }
 
@@ -535,6 +568,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   hipStream_t s = c->stream;
 
   if (!static_memory && stale && (rc = refresh_lookup_copies(c, a, apr, one_size))) return rc;
+  if ((rc = wait_for_lookup_copies(c, apr))) return rc;
 
   const bool timed = stats != nullptr;
   const bool prof = c->profiling && c->prof_frames < c->prof_cap;
@@ -719,6 +753,7 @@ int pbr_destroy(PbrContext* c) {
   free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_live_info); free_dev(c->d_live_tiles); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
   free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);
   free_dev(pr->d_srgb_lut);
+  if (pr->copies_ready) (void)hipEventDestroy(pr->copies_ready);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : c->prof_events) if (ev) (void)hipEventDestroy(ev);
@@ -733,6 +768,7 @@ int pbr_set_stream(PbrContext* c, void* hip_stream) {
   if (!c) return PBR_E_ARG;
   DeviceGuard guard(c->device);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (priv_of(c)->copies_stream == c->stream) priv_of(c)->copies_pending = false;   // (a rebuild queued on the old stream has just completed)
   c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->own_stream;
   return PBR_OK;
 }
@@ -795,13 +831,19 @@ static int upload_mesh_common(PbrContext* c, const float* verts, int32_t n_verts
     HIP_TRY(c, hipMemcpy(c->d_inst_normal, instance_normal, bytes, hipMemcpyHostToDevice));
   }
   c->n_verts = n_verts; c->n_indices = n_indices; c->n_instances = instance_count;
+  // Bounding box of the positions, for skipping whole instances that miss the frame.  A position that is not finite
+  // bounds nothing (its triangles are still drawn or dropped one by one, as the reference's would be): the mesh then
+  // gets the "no box known" state, lo > hi, and no instance is ever skipped.
+  bool all_finite = true;
   for (int k = 0; k < 3; ++k) { c->mesh_lo[k] = verts[k]; c->mesh_hi[k] = verts[k]; }
-  for (int32_t i = 1; i < n_verts; ++i)
+  for (int32_t i = 0; i < n_verts; ++i)
     for (int k = 0; k < 3; ++k) {
       const float v = verts[8 * (size_t)i + k];
-      if (!(v >= c->mesh_lo[k])) c->mesh_lo[k] = v;   // (a NaN coordinate ends up in both bounds, and the box then culls nothing)
-      if (!(v <= c->mesh_hi[k])) c->mesh_hi[k] = v;
+      all_finite = all_finite && std::isfinite(v);
+      if (v < c->mesh_lo[k]) c->mesh_lo[k] = v;
+      if (v > c->mesh_hi[k]) c->mesh_hi[k] = v;
     }
+  if (!all_finite) for (int k = 0; k < 3; ++k) { c->mesh_lo[k] = 1.0f; c->mesh_hi[k] = -1.0f; }
   return PBR_OK;
 }
 
@@ -849,21 +891,28 @@ int pbr_upload_hdr(PbrContext* c, const float* rgba32f, int32_t w, int32_t h) {
   if (!c) return PBR_E_ARG;
   if (!rgba32f || w <= 0 || h <= 0 || w > 32768 || h > 32768) return fail(c, PBR_E_ARG, "bad HDR %dx%d", w, h);
   DeviceGuard guard(c->device);
+  if (level_count(w, h) > PBR_MAX_LEVELS) return fail(c, PBR_E_ARG, "too many mip levels");
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  free_dev(c->d_hdr);
+  // the old image goes first, whole: if an allocation below fails the context holds no HDR (and says so), not half of one
+  free_dev(c->d_hdr); free_dev(c->d_hdr_rgb);
   DevEquirect& e = c->hdr;
-  e.w = w; e.h = h; e.levels = level_count(w, h);   // renderer.ts:1513
-  if (e.levels > PBR_MAX_LEVELS) return fail(c, PBR_E_ARG, "too many mip levels");
+  e = DevEquirect{};
+  priv_of(c)->prefilter_tables_for = -1;
+  const int levels = level_count(w, h);   // renderer.ts:1513
+  uint32_t off[PBR_MAX_LEVELS];
   size_t total;
-  chain_offsets(w, h, e.levels, e.off, &total);
+  chain_offsets(w, h, levels, off, &total);
   HIP_TRY(c, hipMalloc(&c->d_hdr, total * sizeof(float4)));
-  e.base = c->d_hdr;
+  // the prefilter's gathers fetch three floats per source pixel instead of four from this copy
+  if (hipError_t err = hipMalloc(&c->d_hdr_rgb, total * 3 * sizeof(float)); err != hipSuccess) {
+    free_dev(c->d_hdr);
+    return fail(c, PBR_E_DEVICE, "hipMalloc of the HDR's alpha-less copy failed: %s", hipGetErrorString(err));
+  }
+  e.w = w; e.h = h; e.levels = levels;
+  std::memcpy(e.off, off, sizeof off);
+  e.base = c->d_hdr; e.rgb = c->d_hdr_rgb;
   HIP_TRY(c, hipMemcpyAsync(c->d_hdr, rgba32f, (size_t)w * h * sizeof(float4), hipMemcpyHostToDevice, c->stream));
   launch_build_mips_rgba32f(c->stream, c->d_hdr, e.off, w, h, e.levels);
-  // the prefilter's gathers fetch three floats per source pixel instead of four from this copy
-  free_dev(c->d_hdr_rgb);
-  HIP_TRY(c, hipMalloc(&c->d_hdr_rgb, total * 3 * sizeof(float)));
-  e.rgb = c->d_hdr_rgb;
   launch_drop_alpha(c->stream, c->d_hdr, c->d_hdr_rgb, total);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
@@ -986,17 +1035,20 @@ static int prefilter_texel_range(PbrContext* c, int32_t size, int32_t mips, int3
     HIP_TRY(c, hipMemcpy(c->d_samples, host.data(), host.size() * sizeof(PrefilterSample), hipMemcpyHostToDevice));
     pr->prefilter_tables_for = mips; pr->prefilter_src_levels = c->hdr.levels;
   }
+  uint64_t replicated = 0;
   if (shard_count >= 0) {
     std::vector<uint64_t> cuts((size_t)shard_count + 1);
     prefilter_cuts(size, mips, shard_count, cuts.data());
     begin = cuts[shard_index]; end = cuts[shard_index + 1];
+    replicated = cuts[0];
   } else if (begin > end || end > c->pre_total_texels) {
     return fail(c, PBR_E_ARG, "texel range [%llu, %llu) outside the map's %zu texels", (unsigned long long)begin, (unsigned long long)end, c->pre_total_texels);
   }
   for (int m = 0; m < mips; ++m) {
     const size_t s = (size_t)std::max(1, size >> m);
     const size_t lo = c->pre.off[m], hi = lo + 6 * s * s;
-    const size_t a = std::max(lo, (size_t)begin), b = std::min(hi, (size_t)end);
+    // the levels in front of the shards' ranges are filtered whole by every shard (prefilter_cuts)
+    const size_t a = hi <= (size_t)replicated ? lo : std::max(lo, (size_t)begin), b = hi <= (size_t)replicated ? hi : std::min(hi, (size_t)end);
     if (a >= b) continue;
     launch_prefilter(c->stream, c->hdr, c->d_samples + (size_t)m * PBR_PREFILTER_SAMPLES, pr->table_count[m], pr->table_weight[m],
                      c->d_pre + lo, (int)s, (int64_t)(a - lo), (int64_t)(b - a));
@@ -1178,6 +1230,7 @@ int pbr_draw_views_device(PbrContext* c, int32_t n_views, const PbrFrameUniforms
   const bool stale = apr->sky_b.dirty || !apr->sky_b.d || apr->irr_b.dirty || !apr->irr_b.d || apr->pre_b.dirty || !apr->pre_b.d || apr->lut_quad_dirty ||
                      apr->lut_quad_size != a->lut_size || apr->atlas_dirty || !apr->d_atlas;
   if (stale && (rc = refresh_lookup_copies(c, a, apr, true))) return rc;
+  if ((rc = wait_for_lookup_copies(c, apr))) return rc;
 
   const int rows = y1 - y0;
   const int tiles_x = (W + PBR_TILE - 1) / PBR_TILE, tiles_y = (rows + PBR_TILE - 1) / PBR_TILE, n_tiles = tiles_x * tiles_y;
@@ -1193,11 +1246,16 @@ int pbr_draw_views_device(PbrContext* c, int32_t n_views, const PbrFrameUniforms
   share.count = std::min(n_tiles, std::max(0, (int)(n_tiles * PBR_SKY_SHARE_SETUP_PASS)));
   ViewArgs views[PBR_MAX_VIEWS];
   std::memset(views, 0, sizeof views);
+  // everything that can fail comes before anything a failure would leave half done: the counter sets below are flipped
+  // on the promise that this pass's rasteriser re-arms the other set
   for (int v = 0; v < n_views; ++v) {
     PbrContext* w = v == 0 ? c : pr->view_slots[v - 1];   // whose working buffers and counters this view uses
-    PbrContextPrivate* wpr = priv_of(w);
     w->stream = s;                                        // (a slot's buffers are used, and may only be regrown, in this stream's order)
     if ((rc = ensure_frame_buffers(w, W, rows, n_tiles, 1, /*outputs=*/false))) return w == c ? rc : fail(c, rc, "%s", w->error.c_str());
+  }
+  for (int v = 0; v < n_views; ++v) {
+    PbrContext* w = v == 0 ? c : pr->view_slots[v - 1];
+    PbrContextPrivate* wpr = priv_of(w);
     ViewArgs& va = views[v];
     FrameParams& fp = va.fp;
     fp.u = u[v];
@@ -1241,6 +1299,22 @@ int pbr_draw_views_device(PbrContext* c, int32_t n_views, const PbrFrameUniforms
   if (prof) { HIP_TRY(c, hipEventRecord(pe[1], s)); ++c->prof_frames; }
   HIP_TRY(c, hipGetLastError());
   return PBR_OK;
+}
+
+int pbr_release_view_buffers(PbrContext* c) {
+  if (!c) return PBR_E_ARG;
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));   // the slots' buffers are used in this stream's order
+  PbrContextPrivate* pr = priv_of(c);
+  int rc = PBR_OK;
+  for (PbrContext* slot : pr->view_slots) {
+    HIP_TRY(c, hipMemcpy(slot->h_counters, slot->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (check_sticky(slot) && rc == PBR_OK) rc = fail(c, PBR_E_STATE, "%s", slot->error.c_str());   // an overflow of a queued pass is still reported
+    slot->stream = slot->own_stream;
+    (void)pbr_destroy(slot);
+  }
+  pr->view_slots.clear();
+  return rc;
 }
 
 int pbr_draw_frame_static(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1, void* d_rgba8) {

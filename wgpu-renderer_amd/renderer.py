@@ -228,6 +228,10 @@ class Renderer:
         outs = (C.c_void_p * n)(*[C.c_void_p(int(a)) for a in d_rgba8])
         self._check(self._lib.pbr_draw_views_device(self._ctx, n, us, self.width, self.height, y0, y1, outs))
 
+    def release_view_buffers(self):
+        """Frees the working buffers draw_views_device keeps for the second and further views of its passes."""
+        self._check(self._lib.pbr_release_view_buffers(self._ctx))
+
     def render(self):
         """renderer.ts:102-105: init then run; headless `run` is one frame, returned as RGBA8."""
         if not self._ready:

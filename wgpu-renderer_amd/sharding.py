@@ -2,9 +2,11 @@
 partitions exist only where the work divides without changing any result:
 
   * orbit frames      - frame f of a camera path goes to rank f mod world (no exchange)
-  * prefilter shards  - the texels of all prefilter mips, flattened in (mip, face, y, x) order,
+  * prefilter shards  - the levels that are cheaper to filter than to send (roughness 0: level 0, three
+                        quarters of the map's bytes and a fiftieth of its work) are filtered by every rank
+                        for itself; the texels of the other mips, flattened in (mip, face, y, x) order,
                         are cut into `world` ranges of equal cost (the library's own rule,
-                        pbr_ibl_prefilter_partition); the ranges are exchanged with one all-gather
+                        pbr_ibl_prefilter_partition) and only those are exchanged, with one all-gather
   * screen strips     - rank g owns an even-aligned band of rows; bands are gathered to rank 0
 
 Everything here is host arithmetic (the prefilter cuts come from a host-only call of the library) so
@@ -21,9 +23,10 @@ def prefilter_total_texels(size, mips):
 
 
 def prefilter_cuts(size, mips, world):
-    """First texel of every shard plus the total (world + 1 numbers), from the library's own partition
-    (pbr_ibl_prefilter_partition, host arithmetic, no device needed): a texel of level m weighs the GGX
-    samples kept at that level's roughness, so the shards carry equal work, not equal texel counts."""
+    """The library's own partition (pbr_ibl_prefilter_partition, host arithmetic, no device needed), world + 1
+    numbers: cuts[0] texels at the front of the map are filtered by every shard for itself (0 for one shard), shard k
+    owns texels [cuts[k], cuts[k + 1]), cuts[world] is the total.  A texel of level m weighs the GGX samples kept at
+    that level's roughness, so the shards carry equal work, not equal texel counts."""
     import ctypes as C
     from . import _lib
     cuts = (C.c_uint64 * (world + 1))()
@@ -44,15 +47,23 @@ def prefilter_kept_samples(mips):
 
 
 def prefilter_shard_texels(size, mips, rank, world):
-    """[begin, end) in texels; identical to pbr_ibl_prefilter_shard_range / 16 bytes."""
+    """[begin, end) in texels of what only rank `rank` filters, i.e. what it sends; identical to
+    pbr_ibl_prefilter_shard_range / 16 bytes."""
     cuts = prefilter_cuts(size, mips, world)
     return cuts[rank], cuts[rank + 1]
 
 
-def prefilter_padded_chunk(size, mips, world):
-    """All-gather needs equal chunks: the largest shard, in texels."""
+def prefilter_replicated_texels(size, mips, world):
+    """Texels at the front of the map that every rank filters for itself and nobody sends."""
+    return prefilter_cuts(size, mips, world)[0]
+
+
+def prefilter_exchange_bytes(size, mips, world, how="collective"):
+    """Bytes every rank contributes to the exchange of the shards (16 per texel): its own range when the ranges go
+    peer to peer, the largest range when one all-gather of equal chunks carries them."""
     cuts = prefilter_cuts(size, mips, world)
-    return max(e - b for b, e in zip(cuts[:-1], cuts[1:]))
+    own = [16 * (e - b) for b, e in zip(cuts[:-1], cuts[1:])]
+    return own if how == "p2p" else [max(own)] * world
 
 
 def strip_rows(height, rank, world):
