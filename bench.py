@@ -46,8 +46,13 @@ def _newest(*names):
     return os.path.join(ROOT, "profiles", names[-1])
 
 
-TRAFFIC_FILE = _newest("r02_traffic.json", "r01_traffic.json")   # PMC pass of scripts/gpu_traffic.sh over this same workload
-VALU_FILE = _newest("r02_valu.json", "r01_valu.json")            # SQ_INSTS_VALU per launch, from scripts/gpu_pmc_frame.sh
+TRAFFIC_FILE = _newest("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")   # PMC pass of scripts/gpu_traffic.sh over this same workload
+VALU_FILE = _newest("r03_valu.json", "r02_valu.json", "r01_valu.json")                # SQ_INSTS_VALU per launch, from scripts/gpu_pmc_frame.sh
+PREFILTER_COUNTER_FILE = _newest("r03_prefilter_counters.txt", "r02_prefilter_counters.txt")   # scripts/gpu_pmc_prefilter.sh: counters per launch of the prefilter kernels
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X: 256 CUs x 4 SIMDs x 16 lanes x 2 (packed) x 2 (fma) x 2.4 GHz
+PREFILTER_FLOP_PER_SAMPLE = 110   # the survey's fixed count for one sample of prefiltermap.wgsl:131-168 that passes N.L > 0
+PREFILTER_ISSUE_CYCLES_PER_INSTRUCTION = 3.0   # the prefilter loop's compiled instruction mix priced with the measured issue rates (scripts/isa_issue_cost.py)
+XCDS = 8
 FRAME_KERNELS = ["setup_kernel", "raster_kernel", "resolve_surface_fast_kernel"]
 # Vector instructions do not all cost the same issue time: plain f32 add / mul / fma and the simple integer operations
 # retire at about one per 2.3 cycles per SIMD, anything that reads a scalar register, converts, compares or selects at
@@ -118,6 +123,44 @@ def valu_issue(kernels, ms):
         out["texture_address_unit_frac"] = sum(float(table[k]["texture_address_busy_cycles"]) for k in kernels) / (CUS * clock_cycles)
     except KeyError:
         pass
+    return out
+
+
+def prefilter_counters(path=None):
+    """The counters of the prefilter's dominant launch shape (the 1024-thread instantiation: levels 1 to 3 of the
+    2048^2 map, nine tenths of the time) from the committed rocprofv3 summary, per launch: vector instructions, the
+    graphics-active cycles (summed over the eight XCDs by the profiler) and the texture-address units' busy cycles
+    (summed over the 256 units).  Derived: the share of the vector issue slots the launch used at the clock it actually
+    ran at, and the share of time the texture-address units were busy.  None if the file is missing or has another
+    shape."""
+    try:
+        table, kernel = {}, None
+        with open(path or PREFILTER_COUNTER_FILE) as f:
+            for line in f:
+                if " dispatches " in line:
+                    kernel = "1024" if "1024>" in line else "other"
+                    continue
+                parts = line.split()
+                if kernel and len(parts) >= 2 and parts[0][:1].isupper() and "_" in parts[0]:
+                    table.setdefault(kernel, {}).setdefault(parts[0], float(parts[1]))
+        k = table["1024"]
+        cycles = k["GRBM_GUI_ACTIVE"] / XCDS                    # cycles the launch lasted, at the clock it ran at
+        return {"valu_wave_instructions": k["SQ_INSTS_VALU"], "cycles": cycles, "ta_busy_frac": k["TA_TA_BUSY_sum"] / CUS / cycles,
+                "valu_issue_frac": k["SQ_INSTS_VALU"] * PREFILTER_ISSUE_CYCLES_PER_INSTRUCTION / (SIMDS * cycles),
+                "vector_memory_instructions": k.get("SQ_INSTS_VMEM_RD"), "l2_requests": k.get("TCP_TCC_READ_REQ_sum")}
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
+def prefilter_roofline(executed_samples, ms, counters):
+    """The FP32-vector roofline entry of the prefilter: executed flop (samples that contribute x the survey's 110 flop
+    per sample) over the time, against the vector peak; next to it what the counters say bounds the kernel."""
+    tflops = executed_samples * PREFILTER_FLOP_PER_SAMPLE / (ms * 1e-3) / 1e12
+    out = {"bound": "fp32_valu", "achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VECTOR_PEAK_TFLOPS,
+           "executed_flop": executed_samples * PREFILTER_FLOP_PER_SAMPLE, "flop_per_sample": PREFILTER_FLOP_PER_SAMPLE}
+    if counters is not None:
+        out["valu_issue"] = counters["valu_issue_frac"]
+        out["ta_busy"] = counters["ta_busy_frac"]
     return out
 
 
@@ -358,6 +401,14 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
 
     n_iso = min(args.steps, max(V, min(args.steps, 20) // V * V))   # whole passes (a run of fewer steps than views has one shorter pass)
     iso_frames, iso_total, iso_span = isolated(n_iso, V)
+    # all three launches of the same passes, each with the chip to itself (four events per pass)
+    kern_frames, kern_total = C.c_int32(), (C.c_float * 3)()
+    pkg._lib.check(r._ctx, lib.pbr_profile_begin_kernels(r._ctx, n_iso))
+    for lo in range(args.warmup, args.warmup + n_iso, V):
+        draw(r, lanes[0][2], lo, min(lo + V, args.warmup + n_iso))
+    pkg._lib.check(r._ctx, lib.pbr_profile_end_kernels(r._ctx, C.byref(kern_frames), kern_total, None))
+    r.synchronize()
+    kern_ms = [kern_total[k] / max(kern_frames.value, 1) for k in range(3)]
     # the frame with nothing else in flight and no other context on the scene (config 2's "single frame"): the forks go first
     for rr, _, _ in lanes[1:]:
         rr.close()
@@ -401,6 +452,14 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
         frame_traffic = measured_frame_traffic(V, K)
         surf_traffic = measured_traffic(surface_shape(K, V))   # per launch, i.e. for the V views of a pass, in the shape of the timed region
         issue_one = valu_issue(["resolve_surface_fast_kernel"], iso_ms / V)   # the committed counts are per frame
+        # the rasteriser's launch of a pass: it also shades the skybox tiles the set-up launch left (sky_share_setup of
+        # them ride there); its algorithmic bytes are the colour it writes for those background pixels plus the quad
+        # lists it leaves for the surface launch (8 B per uniform quad, 20 B per mixed one: at most 5 B per covered pixel)
+        sky_share_raster = 1.0 - (0.10 if V > 1 else (0.55 if K == 1 else 0.35))
+        raster_bytes = V * (sky_share_raster * (1.0 - c) * npix * 4.0 + c * npix * 5.0)
+        raster_ms = kern_ms[1]
+        raster_gbs = raster_bytes / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else float("nan")
+        raster_name = "raster_views_kernel" if V > 1 else "raster_kernel"
         issue_frame = valu_issue(FRAME_KERNELS, frame_ms)
         result = {
             "metric": "shaded Mpix/s (DamagedHelmet 4K PBR+IBL)",
@@ -433,6 +492,13 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
                                           "note": "one frame per launch, in the kernel's other shape (one 1024-thread workgroup per compute unit), which the library launches for a context without forks"},
                          "in_flight": {"ms": surf_ms, "achieved": in_flight_gbs, "frac": in_flight_gbs / HBM_PEAK_GBS,
                                        "note": "event-to-event time of the kernel inside the timed region, stretched by the other frames in flight"}},
+            "roofline_raster": {"bound": "hbm", "kernel": raster_name, "launch_ms": raster_ms, "achieved": raster_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": raster_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(raster_name), "algorithmic_bytes": raster_bytes, "views_per_launch": V,
+                                "note": "the pass's second launch, alone on the chip: tile rasteriser plus the skybox colour of the tiles the set-up launch did not take; "
+                                        "as long as the surface launch, so the frame has two dominant kernels",
+                                "bound_measured": "vector issue of the skybox arithmetic (62 instructions per pixel) and its 16 twelve-byte taps per thread; the tiles with geometry wait on their per-triangle loops",
+                                "valu_issue": valu_issue(["raster_kernel"], raster_ms / V)},
+            "kernel_ms_alone_per_pass": {"setup": kern_ms[0], "raster": kern_ms[1], "surface": kern_ms[2]},
             "frame_roofline": {"bound": "hbm", "kernels": "all kernels of one frame (setup + sky, raster + sky, surface); wall time per frame with the configured frames in flight",
                                "achieved": frame_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frame_gbs / HBM_PEAK_GBS, "algorithmic_bytes": frame_bytes,
                                "traffic": frame_traffic,
@@ -462,30 +528,63 @@ def run_strips(args, pkg, torch, dist, ctxinfo):
     r.set_stream(stream.cuda_stream)
     torch.cuda.set_stream(stream)
     y0, y1 = sharding.strip_rows(H, rank, world)
-    strip = torch.empty((y1 - y0, W, 4), dtype=torch.uint8, device=dev)
+    # Two strip targets (and on rank 0 two frames): while frame i's strips travel, frame i + 1 is rendered into the other
+    # target.  The render runs on the context's stream, the gather behind an event on a second stream; a target is
+    # reused only after the gather that read it (two frames earlier) has finished.  No host synchronisation per frame.
+    strips = [torch.empty((y1 - y0, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)]
+    frames_out = [torch.empty((H, W, 4), dtype=torch.uint8, device=dev) for _ in range(2)] if (use_dist and rank == 0) else [None, None]
+    comm_stream = frame_streams[1] if len(frame_streams) > 1 else torch.cuda.Stream(dev)
+    strip = strips[0]
     n_local = args.warmup + args.steps
     uniforms = []
     for _ in range(n_local):
         uniforms.append(r.frame_uniforms())
         r.camera.update_camera_rotation(-10.0, 0.0)
-    t_render, t_gather = [0.0], [0.0]
+    rendered = [torch.cuda.Event() for _ in range(2)]
+    gathered = [torch.cuda.Event() for _ in range(2)]
+    timing = {"render": [], "gather": []}          # (begin, end) event pairs of the timed steps
     frame_box = [None]
+    serial = bool(os.environ.get("PBR_STRIPS_SERIAL"))   # for comparison: render, wait, gather, wait (what round 2 timed)
 
     def step(i, timed=True):
-        a = time.perf_counter()
-        r.draw_frame_device(strip.data_ptr(), y0=y0, y1=y1, uniforms=uniforms[i])
-        stream.synchronize()
-        b = time.perf_counter()
-        frame_box[0] = parallel.gather_strips(strip, H, W, rank, world, dst=0) if use_dist else strip
-        torch.cuda.synchronize(dev)
+        k = i & 1
+        if i >= 2:
+            stream.wait_event(gathered[k])                       # the gather of frame i - 2 has read this target
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if timed:
-            t_render[0] += b - a
-            t_gather[0] += time.perf_counter() - b
+            ev[0].record(stream)
+        r.draw_frame_device(strips[k].data_ptr(), y0=y0, y1=y1, uniforms=uniforms[i])
+        if timed:
+            ev[1].record(stream)
+        rendered[k].record(stream)
+        if serial:
+            stream.synchronize()
+        if use_dist:
+            comm_stream.wait_event(rendered[k])
+            with torch.cuda.stream(comm_stream):
+                if timed:
+                    ev[2].record(comm_stream)
+                frame_box[0] = parallel.gather_strips(strips[k], H, W, rank, world, dst=0, out=frames_out[k])
+                if timed:
+                    ev[3].record(comm_stream)
+                gathered[k].record(comm_stream)
+        else:
+            frame_box[0] = strips[k]
+            gathered[k].record(stream)
+        if serial:
+            torch.cuda.synchronize(dev)
+        if timed:
+            timing["render"].append((ev[0], ev[1]))
+            if use_dist:
+                timing["gather"].append((ev[2], ev[3]))
 
     for i in range(args.warmup):
         step(i, timed=False)
+    torch.cuda.synchronize(dev)
     elapsed = timed_region(torch, dist, use_dist, dev, args.steps, lambda i: step(args.warmup + i))
     r.synchronize()
+    render_ms = sum(a.elapsed_time(b) for a, b in timing["render"]) / max(len(timing["render"]), 1)
+    gather_ms = sum(a.elapsed_time(b) for a, b in timing["gather"]) / max(len(timing["gather"]), 1) if timing["gather"] else 0.0
     stats = pkg._lib.FrameStats()
     r.draw_frame_device(strip.data_ptr(), y0=y0, y1=y1, uniforms=uniforms[args.warmup], stats=stats)
     result = None
@@ -499,8 +598,12 @@ def run_strips(args, pkg, torch, dist, ctxinfo):
             "config": {"workload": f"synthetic stress: 10x10 instanced DamagedHelmet ({models.shape[0] * r.geometries[0].indices.size // 3} triangles) at {W}x{H}, "
                                    f"{world} even-aligned row strips, one per rank, gathered to rank 0", "parallelism": f"screen strips x{world}",
                        "rank0_rows": [y0, y1], "rank0_setup_triangles": int(stats.setup_triangles), "rank0_covered_fraction_of_strip": stats.covered_pixels / float((y1 - y0) * W)},
-            "render_ms_rank0": t_render[0] / args.steps * 1e3, "gather_ms_rank0": t_gather[0] / args.steps * 1e3,
-            "exchange": "none (one rank)" if not use_dist else f"gather of {world} rgba8 bands ({npix * 4 / 1e6:.0f} MB per frame) to rank 0 over RCCL",
+            # device time of this rank's render and of the gather as rank 0 sees it (events on their streams); a step
+            # that hid one behind the other takes about the longer of the two, not their sum
+            "render_ms_rank0": render_ms, "gather_ms_rank0": gather_ms, "overlap_ms_rank0": max(0.0, render_ms + gather_ms - frame_ms),
+            "pipelined": not serial,
+            "exchange": "none (one rank)" if not use_dist else f"gather of {world} rgba8 bands ({npix * 4 / 1e6:.0f} MB per frame) to rank 0 over RCCL, received straight into the frame's rows; "
+                                                                "frame i + 1 is rendered while frame i's bands travel (two targets, two streams)",
         }
     return r, [(r, stream, strip)], result
 
@@ -536,7 +639,7 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
             info["replicated_texels"] = cuts[0]
             info["exchange_bytes_per_rank"] = sharding.prefilter_exchange_bytes(size, mips, world, how)
             info["exchange_bytes_rank0_sent"] = sent[0]
-            info["exchange"] = (f"every rank filters the first {cuts[0]} texels (roughness 0) for itself; the other {(texels - cuts[0]) * 16 / 1e6:.0f} MB of the "
+            info["exchange"] = "none (one rank)" if world == 1 else (f"every rank filters the first {cuts[0]} texels (roughness 0) for itself; the other {(texels - cuts[0]) * 16 / 1e6:.0f} MB of the "
                                 f"{texels * 16 / 1e6:.0f} MB map are cut by cost and exchanged ("
                                 + ("one all-gather of equal chunks, staging kept between calls" if how != "p2p" else "peer to peer, in place")
                                 + "), included in ms")
@@ -547,7 +650,10 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
                      "reference_samples": texels * 1024, "reference_gsamples_per_s": texels * 1024 / (ms * 1e-3) / 1e9,
                      # work executed: roughness 0 collapses to one sample per texel and samples with N.L <= 0 contribute nothing
                      "executed_samples": executed, "executed_gsamples_per_s": executed / (ms * 1e-3) / 1e9, "kept_samples_per_level": kept,
-                     "bound_measured": "latency of the requests that leave L1 (two 12-byte gathers per sample, 5 L2 requests per wavefront load) times the loads a compute unit keeps in flight; texture-address units three quarters busy; see profiles/r02_prefilter_counters.txt"})
+                     "roofline": prefilter_roofline(executed, ms, prefilter_counters()),
+                     "bound_measured": "vector issue: the counted launch used nearly every issue slot of the clock it ran at (about 2.0 GHz under this load, "
+                                       "against the 2.4 GHz peak the roofline is priced at), with the texture-address units three quarters busy beside it; "
+                                       "see " + os.path.relpath(PREFILTER_COUNTER_FILE, ROOT)})
     except Exception as exc:                             # the frame benchmark above stands on its own
         info["error"] = f"{type(exc).__name__}: {exc}"
     if rank == 0 and result is not None:

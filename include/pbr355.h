@@ -233,6 +233,11 @@ int pbr_debug_depth(PbrContext* ctx, float* depth_out, size_t n_floats);
  * in the reference beyond its timestamp query (renderer.ts:1968-1974). ---- */
 int pbr_profile_begin(PbrContext* ctx, int32_t max_frames);
 int pbr_profile_end(PbrContext* ctx, int32_t* frames, float* surface_ms_total, float* span_ms);
+/* The same for all three launches of a frame (or of a pbr_draw_views_device pass, which counts as one frame): four
+ * events per frame, kernel_ms_total[3] = summed durations of the set-up, raster and surface-shading launches.  The
+ * events take stream time; meant for frames drawn one at a time, after a timed region, not inside one. */
+int pbr_profile_begin_kernels(PbrContext* ctx, int32_t max_frames);
+int pbr_profile_end_kernels(PbrContext* ctx, int32_t* frames, float* kernel_ms_total, float* span_ms);
 
 #ifdef __cplusplus
 }

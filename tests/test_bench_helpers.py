@@ -97,6 +97,40 @@ def test_result_names_what_was_measured():
     assert frame is not None and launch is not None and frame > launch / a.views   # a frame is more than its share of the surface launch
 
 
+def test_prefilter_roofline_reproduces_from_the_committed_counters():
+    """`ibl_prefilter.roofline`: the fraction is executed samples x 110 flop over the time against the 157.3 TFLOP/s vector
+    peak, and its two utilisation figures are derived from the committed counter summary exactly this way."""
+    b = _bench()
+    c = b.prefilter_counters()
+    assert c is not None
+    table = {}
+    with open(b.PREFILTER_COUNTER_FILE) as f:
+        shape = None
+        for line in f:
+            if " dispatches " in line:
+                shape = "1024>" in line
+            elif shape and len(line.split()) >= 2:
+                table.setdefault(line.split()[0], float(line.split()[1]))
+    cycles = table["GRBM_GUI_ACTIVE"] / 8                       # the profiler sums the eight XCDs' counters
+    assert abs(c["ta_busy_frac"] - table["TA_TA_BUSY_sum"] / 256 / cycles) < 1e-12
+    assert abs(c["valu_issue_frac"] - table["SQ_INSTS_VALU"] * 3.0 / (1024 * cycles)) < 1e-12
+    assert 0.5 < c["ta_busy_frac"] < 1.0 and 0.6 < c["valu_issue_frac"] <= 1.05
+    r = b.prefilter_roofline(8_600_000_000, 15.5, c)
+    assert r["bound"] == "fp32_valu" and r["peak"] == 157.3 and r["unit"] == "TFLOP/s"
+    assert abs(r["frac"] - 8.6e9 * 110 / 15.5e-3 / 1e12 / 157.3) < 1e-12 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-12
+    assert r["valu_issue"] == c["valu_issue_frac"] and r["ta_busy"] == c["ta_busy_frac"]
+    assert b.prefilter_counters("/nonexistent") is None
+
+
+def test_result_has_a_roofline_for_each_dominant_kernel_and_each_headline():
+    text = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('"roofline_raster"', '"kernel_ms_alone_per_pass"', '"roofline": prefilter_roofline(', '"exchange_bytes_per_rank"', '"replicated_texels"'):
+        assert key in text, key
+    b = _bench()
+    assert b.measured_traffic("raster_views_kernel") is not None      # the raster entry's `traffic`
+    assert b.valu_issue(["raster_kernel"], 0.025) is not None         # and its `valu_issue`
+
+
 def test_passes_cover_every_step_exactly_once():
     """Whatever the step count, the views per pass and the contexts in flight: the passes submitted over the steps of a
     region draw each of its frames once, none twice, none of another region; contexts take the passes in turn."""

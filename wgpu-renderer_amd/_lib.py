@@ -67,6 +67,8 @@ EXPORTS = {
     "pbr_debug_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "pbr_profile_begin": (C.c_int, [C.c_void_p, C.c_int32]),
     "pbr_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "pbr_profile_begin_kernels": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pbr_profile_end_kernels": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
 }
 
 _lib = None

@@ -572,7 +572,9 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
 
   const bool timed = stats != nullptr;
   const bool prof = c->profiling && c->prof_frames < c->prof_cap;
-  hipEvent_t* pe = prof ? &c->prof_events[2 * c->prof_frames] : nullptr;   // surface pass begin, end
+  const int prof_stride = c->prof_all ? 4 : 2;
+  hipEvent_t* pe = prof ? &c->prof_events[prof_stride * c->prof_frames] + (prof_stride - 2) : nullptr;   // surface pass begin, end
+  if (prof && c->prof_all) HIP_TRY(c, hipEventRecord(pe[-2], s));
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[0], s));
   uint8_t* color = static_cast<uint8_t*>(d_rgba8);
 
@@ -606,6 +608,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   launch_setup_and_bin(s, dp, source, a->d_indices, fw.setup, fw.records, (uint32_t)fw.setup_cap, fw.tile_count, fw.bins, fw.overflow,
                        (uint32_t)fw.overflow_cap, counters, fw.live, a->n_indices / 3, a->n_instances, sky_b);
   if (timed) HIP_TRY(c, hipEventRecord(c->ev[2], s));
+  if (prof && c->prof_all) HIP_TRY(c, hipEventRecord(pe[-1], s));
   uint32_t* vis = d_vis ? static_cast<uint32_t*>(d_vis) : c->d_vis;
   // the visibility buffer is only written when someone will read it: the caller (vis output) or the
   // coverage count of the statistics
@@ -1283,7 +1286,12 @@ int pbr_draw_views_device(PbrContext* c, int32_t n_views, const PbrFrameUniforms
     w->last_w = W; w->last_rows = rows; w->last_samples = 1;
     ++wpr->frames_drawn;
   }
+  const bool prof = c->profiling && c->prof_frames < c->prof_cap;
+  const int prof_stride = c->prof_all ? 4 : 2;
+  hipEvent_t* pe = prof ? &c->prof_events[prof_stride * c->prof_frames] + (prof_stride - 2) : nullptr;   // the pass's launches count as one profiled frame
+  if (prof && c->prof_all) HIP_TRY(c, hipEventRecord(pe[-2], s));
   launch_setup_views(s, views, n_views, a->d_indices, a->n_indices / 3, a->n_instances, share);
+  if (prof && c->prof_all) HIP_TRY(c, hipEventRecord(pe[-1], s));
   launch_raster_views(s, views, n_views, apr->sky_b.cube, share.first + share.count, tiles_x, tiles_y, PBR_LIVE_TILE_CAP);
   ResolveInputs in;
   in.records = nullptr; in.vout = a->d_vout; in.indices = a->d_indices;
@@ -1291,8 +1299,6 @@ int pbr_draw_views_device(PbrContext* c, int32_t n_views, const PbrFrameUniforms
   in.irr = a->irr; in.pre = a->pre; in.sky = a->sky;
   in.irr_b = apr->irr_b.cube; in.pre_b = apr->pre_b.cube; in.sky_b = apr->sky_b.cube;
   in.lut = a->d_lut; in.lut_quad = apr->d_lut_quad; in.atlas = apr->d_atlas; in.lut_size = a->lut_size;
-  const bool prof = c->profiling && c->prof_frames < c->prof_cap;
-  hipEvent_t* pe = prof ? &c->prof_events[2 * c->prof_frames] : nullptr;   // the pass's surface launch counts as one profiled frame
   if (prof) HIP_TRY(c, hipEventRecord(pe[0], s));
   const bool alone = c->parent == nullptr && c->children == 0;
   launch_surface_views(s, views, n_views, in, pr->d_srgb_lut, pr->surface_blocks, /*shared_chip=*/!alone);
@@ -1440,34 +1446,50 @@ int pbr_debug_depth(PbrContext* c, float* depth_out, size_t n_floats) {
   return PBR_OK;
 }
 
-int pbr_profile_begin(PbrContext* c, int32_t max_frames) {
+static int profile_begin(PbrContext* c, int32_t max_frames, bool all) {
   if (!c || max_frames <= 0 || max_frames > (1 << 20)) return c ? fail(c, PBR_E_ARG, "bad frame count") : PBR_E_ARG;
   DeviceGuard guard(c->device);
-  while ((int)c->prof_events.size() < 2 * max_frames) {
+  while ((int)c->prof_events.size() < (all ? 4 : 2) * max_frames) {
     hipEvent_t ev;
     HIP_TRY(c, hipEventCreate(&ev));
     c->prof_events.push_back(ev);
   }
-  c->prof_cap = max_frames; c->prof_frames = 0; c->profiling = true;
+  c->prof_cap = max_frames; c->prof_frames = 0; c->profiling = true; c->prof_all = all;
+  return PBR_OK;
+}
+
+int pbr_profile_begin(PbrContext* c, int32_t max_frames) { return profile_begin(c, max_frames, false); }
+int pbr_profile_begin_kernels(PbrContext* c, int32_t max_frames) { return profile_begin(c, max_frames, true); }
+
+int pbr_profile_end_kernels(PbrContext* c, int32_t* frames, float* kernel_ms_total, float* span_ms) {
+  if (!c) return PBR_E_ARG;
+  DeviceGuard guard(c->device);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const int stride = c->prof_all ? 4 : 2;
+  float total[3] = {0, 0, 0}, span = 0;
+  for (int i = 0; i < c->prof_frames; ++i) {
+    hipEvent_t* e = &c->prof_events[stride * i];
+    // four events: set-up begin, raster begin, surface begin, end; two events: surface begin, end
+    for (int k = c->prof_all ? 0 : 2; k < 3; ++k) {
+      const int first = c->prof_all ? k : 0;
+      float ms = 0;
+      HIP_TRY(c, hipEventElapsedTime(&ms, e[first], e[first + 1]));
+      total[k] += ms;
+    }
+  }
+  if (c->prof_frames > 1) HIP_TRY(c, hipEventElapsedTime(&span, c->prof_events[stride - 1], c->prof_events[stride * c->prof_frames - 1]));
+  if (frames) *frames = c->prof_frames;
+  if (kernel_ms_total) for (int k = 0; k < 3; ++k) kernel_ms_total[k] = total[k];
+  if (span_ms) *span_ms = span;
+  c->profiling = false; c->prof_all = false;
   return PBR_OK;
 }
 
 int pbr_profile_end(PbrContext* c, int32_t* frames, float* surface_ms_total, float* span_ms) {
-  if (!c) return PBR_E_ARG;
-  DeviceGuard guard(c->device);
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
-  float surface = 0, span = 0;
-  for (int i = 0; i < c->prof_frames; ++i) {
-    float ms = 0;
-    HIP_TRY(c, hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
-    surface += ms;
-  }
-  if (c->prof_frames > 1) HIP_TRY(c, hipEventElapsedTime(&span, c->prof_events[1], c->prof_events[2 * c->prof_frames - 1]));
-  if (frames) *frames = c->prof_frames;
-  if (surface_ms_total) *surface_ms_total = surface;
-  if (span_ms) *span_ms = span;
-  c->profiling = false;
-  return PBR_OK;
+  float total[3] = {0, 0, 0};
+  const int rc = pbr_profile_end_kernels(c, frames, total, span_ms);
+  if (rc == PBR_OK && surface_ms_total) *surface_ms_total = total[2];
+  return rc;
 }
 
 }  // extern "C"

@@ -169,8 +169,9 @@ struct PbrContext {
   // timing
   hipEvent_t ev[6] = {};
   bool profiling = false;
-  std::vector<hipEvent_t> prof_events;   // 4 per frame: frame start, raster start, resolve start, end
+  std::vector<hipEvent_t> prof_events;   // per profiled frame: surface launch begin, end; with prof_all: set-up begin, raster begin, surface begin, end
   int32_t prof_frames = 0, prof_cap = 0;
+  bool prof_all = false;                 // pbr_profile_begin_kernels: all three launches of a frame are bracketed
 };
 
 // ---- kernel launchers (defined in the .hip files) ----
