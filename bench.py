@@ -51,7 +51,7 @@ VALU_FILE = _newest("r03_valu.json", "r02_valu.json", "r01_valu.json")          
 PREFILTER_COUNTER_FILE = _newest("r03_prefilter_counters.txt", "r02_prefilter_counters.txt")   # scripts/gpu_pmc_prefilter.sh: counters per launch of the prefilter kernels
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X: 256 CUs x 4 SIMDs x 16 lanes x 2 (packed) x 2 (fma) x 2.4 GHz
 PREFILTER_FLOP_PER_SAMPLE = 110   # the survey's fixed count for one sample of prefiltermap.wgsl:131-168 that passes N.L > 0
-PREFILTER_ISSUE_CYCLES_PER_INSTRUCTION = 3.0   # the prefilter loop's compiled instruction mix priced with the measured issue rates (scripts/isa_issue_cost.py)
+PREFILTER_ISSUE_CYCLES_PER_INSTRUCTION = 2.94  # the prefilter's two sample loops' compiled instruction mix priced with the measured issue rates (scripts/isa_issue_cost.py)
 XCDS = 8
 FRAME_KERNELS = ["setup_kernel", "raster_kernel", "resolve_surface_fast_kernel"]
 # Vector instructions do not all cost the same issue time: plain f32 add / mul / fma and the simple integer operations
@@ -622,7 +622,7 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
     texels = sum(level_texels)
     info = {"config": f"{size}^2 cube, {mips} mips, 1024 samples/texel", "n_gpus": world}
     try:
-        how = os.environ.get("PBR_PREFILTER_EXCHANGE", "collective")
+        how = os.environ.get("PBR_PREFILTER_EXCHANGE", "p2p")
         sent = [0]
 
         def once():
@@ -651,7 +651,7 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
                      # work executed: roughness 0 collapses to one sample per texel and samples with N.L <= 0 contribute nothing
                      "executed_samples": executed, "executed_gsamples_per_s": executed / (ms * 1e-3) / 1e9, "kept_samples_per_level": kept,
                      "roofline": prefilter_roofline(executed, ms, prefilter_counters()),
-                     "bound_measured": "vector issue: the counted launch used nearly every issue slot of the clock it ran at (about 2.0 GHz under this load, "
+                     "bound_measured": "vector issue: the counted launch used nine tenths of the issue slots of the clock it ran at (about 2.0 GHz under this load, "
                                        "against the 2.4 GHz peak the roofline is priced at), with the texture-address units three quarters busy beside it; "
                                        "see " + os.path.relpath(PREFILTER_COUNTER_FILE, ROOT)})
     except Exception as exc:                             # the frame benchmark above stands on its own

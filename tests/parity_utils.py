@@ -51,10 +51,25 @@ class OracleScene:
         self.sky_size, self.irr_size, self.pre_size, self.pre_mips, self.lut_size = sky_size, irr_size, pre_size, pre_mips, lut_size
         self.inst_model = None if instance_models is None else np.ascontiguousarray(instance_models, dtype=np.float32).reshape(-1, 16)
         self.inst_normal = None if instance_normals is None else np.ascontiguousarray(instance_normals, dtype=np.float32).reshape(-1, 16)
-        self._maps = None
+        self._maps = None      # maps to shade from when set (use_maps); the oracle's own otherwise
+        self._own = None
+
+    def use_maps(self, maps):
+        """From now on shade from the given IBL maps (same keys and shapes as own_maps()), e.g. the ones the device
+        generated: the maps' own parity is a separate test (every texel within 1e-3 of the interval the oracle's
+        samples can reach), and a frame shaded by both sides from the same maps differs only by what the frame path
+        does differently - not by a map texel whose sample next to the sun fell on the neighbouring source pixel."""
+        cube = lambda n: (6, n, n, 4)
+        assert maps["sky"].shape == cube(self.sky_size) and maps["irr"].shape == cube(self.irr_size) and maps["lut"].shape == (self.lut_size, self.lut_size, 4)
+        assert [p.shape for p in maps["pre"]] == [cube(max(1, self.pre_size >> m)) for m in range(self.pre_mips)]
+        assert maps["sky"].dtype == maps["irr"].dtype == np.float32 and maps["lut"].dtype == np.uint16 and all(p.dtype == np.float32 for p in maps["pre"])
+        self._maps = maps
 
     def maps(self):
-        if self._maps is None:
+        return self._maps if self._maps is not None else self.own_maps()
+
+    def own_maps(self):
+        if self._own is None:
             h = self.hdr
             sky = ob.equirect_to_cube(self.hdr_data, h.width, h.height, self.sky_size)
             irr = ob.irradiance(self.hdr_data, h.width, h.height, self.irr_size)
@@ -63,22 +78,19 @@ class OracleScene:
                 rough = np.float32(m / (self.pre_mips - 1)) if self.pre_mips > 1 else np.float32(0.0)
                 pre_levels.append(ob.prefilter_level(self.hdr_chain, h.width, h.height, self.hdr_levels, max(1, self.pre_size >> m), rough))
             _, lut16 = ob.brdf_lut(self.lut_size)
-            self._maps = {"sky": sky, "irr": irr, "pre": pre_levels, "lut": lut16}
-        return self._maps
+            self._own = {"sky": sky, "irr": irr, "pre": pre_levels, "lut": lut16}
+        return self._own
 
     @contextlib.contextmanager
     def with_maps(self, maps):
         """Shade from the given IBL maps (same keys and shapes as maps()) instead of the oracle's own: with the maps
         another implementation generated, the frames differ only by what the frame path itself does differently."""
-        own = self.maps()
-        for k in ("sky", "irr", "lut"):
-            assert maps[k].shape == own[k].shape and maps[k].dtype == own[k].dtype, k
-        assert [p.shape for p in maps["pre"]] == [p.shape for p in own["pre"]]
-        self._maps = maps
+        before = self._maps
+        self.use_maps(maps)
         try:
             yield self
         finally:
-            self._maps = own
+            self._maps = before
 
     def c_scene(self):
         m = self.maps()
@@ -178,6 +190,9 @@ class SmallScene:
         self.width, self.height = width, height
         if gpu:
             r.init()
+            # frames are shaded by both sides from the maps the device generated (see OracleScene.use_maps); tests of
+            # the maps themselves ask for oracle.own_maps()
+            self.oracle.use_maps(self.gpu_maps())
         return self
 
     def uniforms(self):

@@ -113,7 +113,7 @@ def test_prefilter_roofline_reproduces_from_the_committed_counters():
                 table.setdefault(line.split()[0], float(line.split()[1]))
     cycles = table["GRBM_GUI_ACTIVE"] / 8                       # the profiler sums the eight XCDs' counters
     assert abs(c["ta_busy_frac"] - table["TA_TA_BUSY_sum"] / 256 / cycles) < 1e-12
-    assert abs(c["valu_issue_frac"] - table["SQ_INSTS_VALU"] * 3.0 / (1024 * cycles)) < 1e-12
+    assert abs(c["valu_issue_frac"] - table["SQ_INSTS_VALU"] * b.PREFILTER_ISSUE_CYCLES_PER_INSTRUCTION / (1024 * cycles)) < 1e-12 and 2.3 <= b.PREFILTER_ISSUE_CYCLES_PER_INSTRUCTION <= 4.0
     assert 0.5 < c["ta_busy_frac"] < 1.0 and 0.6 < c["valu_issue_frac"] <= 1.05
     r = b.prefilter_roofline(8_600_000_000, 15.5, c)
     assert r["bound"] == "fp32_valu" and r["peak"] == 157.3 and r["unit"] == "TFLOP/s"

@@ -224,23 +224,28 @@ def test_prefilter_shards_carry_equal_cost(pkg):
     """The shards of the large prefilter (2048^2, 10 levels) must be balanced in work, not in texels: level 0 is three
     quarters of the texels and, at roughness 0, one sample each.  Cost model: kept samples per texel (counted here
     in float64 independently of the library) times the per-sample factors measured on MI355X for the +-Y faces and
-    the rougher levels (profiles/r02_prefilter_shards.json)."""
+    the rougher levels, for the lane split of the small levels and for the floor of a launch
+    (profiles/r03_prefilter_shards.json)."""
     sh = __import__("wgpu_renderer_amd.sharding", fromlist=["x"])
     size, mips = 2048, 10
     kept = [1 if m == 0 else kept_samples_f64(np.float32(m / (mips - 1))) for m in range(mips)]
     lib_kept = sh.prefilter_kept_samples(mips)
     assert lib_kept[0] == 1 and all(abs(a - b) <= 2 for a, b in zip(kept, lib_kept)), (kept, lib_kept)
 
-    def factors(m):   # (side faces, +-Y faces)
+    def texel_cost(m, face):   # the library's cost model restated: picoseconds per texel
         r = m / (mips - 1)
-        return (1.0, 1.0) if m == 0 else (1.0, 1.41) if r <= 0.17 else (1.24, 2.07) if r <= 0.28 else (1.37, 1.44)
+        level_texels = 6 * (size >> m) ** 2
+        pole = face in (2, 3)
+        scatter = (1.45 if pole else 1.0) if r <= 0.17 else (2.55 if pole else 1.47) if r <= 0.28 else (1.70 if pole else 1.60)
+        shape = 1.0 if level_texels >= 1 << 18 else 1.85 if level_texels >= 1 << 14 else 1.60
+        return (kept[m] + 8) * 1.22 * scatter * shape + 8.5e6 / level_texels
 
     segments = []     # (first texel, texel count, cost per texel, samples per texel) of every face of every level
     first = 0
     for m in range(mips):
         n = (size >> m) ** 2
         for face in range(6):
-            segments.append((first, n, (kept[m] + 8) * factors(m)[1 if face in (2, 3) else 0], kept[m]))
+            segments.append((first, n, texel_cost(m, face), kept[m]))
             first += n
     total_texels = first
 
@@ -254,7 +259,7 @@ def test_prefilter_shards_carry_equal_cost(pkg):
         costs = [load(b, e, 2) for b, e in zip(cuts, cuts[1:])]
         assert max(costs) / (sum(costs) / world) <= 1.02, (world, costs)
         samples = [load(b, e, 3) for b, e in zip(cuts, cuts[1:])]          # without the measured factors: still no idle shard
-        assert max(samples) / (sum(samples) / world) <= 1.45, (world, samples)
+        assert max(samples) / (sum(samples) / world) <= 1.6, (world, samples)
         assert [sh.prefilter_shard_texels(size, mips, r, world) for r in range(world)] == list(zip(cuts, cuts[1:]))
     # the reference's own size: five levels of 128^2
     for world in (2, 4, 8):
@@ -276,12 +281,14 @@ def test_prefilter_exchange_carries_only_what_is_worth_sending(pkg):
         cuts = sh.prefilter_cuts(size, mips, world)
         own = [16 * (e - b) for b, e in zip(cuts, cuts[1:])]
         assert sum(own) == 16 * (total - 6 * size * size) == 134_217_216
-        for how in ("collective", "p2p"):
+        for how in ("p2p", "collective"):
             sent = sh.prefilter_exchange_bytes(size, mips, world, how)
             assert len(sent) == world and all(s >= o for s, o in zip(sent, own))
             assert max(sent) <= 25e6 * 8 / world, (world, how, sent)
-            assert max(sent) / (sum(own) / world) <= 1.3, (world, how, sent)
-        assert sh.prefilter_exchange_bytes(size, mips, world, "p2p") == own
+        # the default exchange sends the ranges as they are: on average exactly the mean; the equal-chunk all-gather
+        # pads every rank's range to the largest, which equal cost puts up to a third above the mean
+        assert sh.prefilter_exchange_bytes(size, mips, world) == sh.prefilter_exchange_bytes(size, mips, world, "p2p") == own
+        assert sum(own) / world * 1.0 <= max(own) <= 1.4 * sum(own) / world
     assert sh.prefilter_exchange_bytes(size, mips, 1) == [16 * total]
 
 

@@ -7,6 +7,7 @@
 #include "pbr_internal.h"
 #include "devmath.h"
 #include "equirect_math.h"
+#include <type_traits>
 
 namespace {
 
@@ -166,13 +167,10 @@ __global__ void __launch_bounds__(256) irradiance_kernel(DevEquirect hdr, const 
   }
 }
 
-// Light direction of one tabulated sample in world space.  The equirect pixel a sample reads flips with the last
-// bit of this sum, so its rounding is spelled out (first two terms fused, the third product rounded on its own)
-// instead of being left to the compiler's choice of contractions.
+// Light direction of one tabulated sample in world space: three multiply-add chains.
 PBR_DEV V3 sample_to_world(const V3& T, const V3& B, const V3& N, float lx, float ly, float lz) {
-#pragma clang fp contract(off)
-  const float nx = N.x * lz, ny = N.y * lz, nz = N.z * lz;
-  return v3(fmaf(ly, B.x, T.x * lx) + nx, fmaf(ly, B.y, T.y * lx) + ny, fmaf(ly, B.z, T.z * lx) + nz);
+#pragma clang fp contract(fast)
+  return v3(fmaf(lz, N.x, fmaf(ly, B.x, T.x * lx)), fmaf(lz, N.y, fmaf(ly, B.y, T.y * lx)), fmaf(lz, N.z, fmaf(ly, B.z, T.z * lx)));
 }
 
 // GGX prefilter of one cube level.  SPLIT lanes share a texel and stride the sample table; the
@@ -197,16 +195,21 @@ PBR_DEV int clamp_to(int x, int top) {
 
 template <int SPLIT, bool POW2, int THREADS = 256>
 __global__ void __launch_bounds__(THREADS)
-prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples, float total_weight, float4* __restrict__ out, int size,
+prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples, int n_single, float total_weight, float4* __restrict__ out, int size,
                  long long first, long long count) {
   constexpr int kThreads = THREADS;
-  // per sample {lx, ly, lz, wa}, {wc, width and height of source level l0 as floats, unused}
+  // per sample {lx, ly, lz, wa}, {kx, cx, ky, cy}: the pixel coordinates in source level l0 are theta * kx + cx and
+  // asin(y) * ky + cy, i.e. (angle * scale + 0.5) * size of equirectangular.wgsl:68-69 with the size multiplied in (for
+  // power-of-two sizes the same bits: scaling by a power of two commutes with the rounding); and wc on its own
   __shared__ float4 s_table[SPLIT == 1 ? 2 * PBR_PREFILTER_SAMPLES : 1];
+  __shared__ float s_wc[SPLIT == 1 ? PBR_PREFILTER_SAMPLES : 1];
   if constexpr (SPLIT == 1) {
     for (int i = threadIdx.x; i < n_samples; i += kThreads) {
       const PrefilterSample s = samples[i];
+      const float w0f = (float)max(1, hdr.w >> s.l0), h0f = (float)max(1, hdr.h >> s.l0);
       s_table[2 * i] = make_float4(s.lx, s.ly, s.lz, s.wa);
-      s_table[2 * i + 1] = make_float4(s.wc, (float)max(1, hdr.w >> s.l0), (float)max(1, hdr.h >> s.l0), 0.0f);
+      s_table[2 * i + 1] = make_float4(INV_ATAN_X * w0f, 0.5f * w0f, INV_ATAN_Y * h0f, 0.5f * h0f);
+      s_wc[i] = s.wc;
     }
     __syncthreads();
   }
@@ -246,63 +249,95 @@ prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, i
   // the two scale factors of equirectangular.wgsl:2 held in vector registers (see the note on issue rates above)
   float inv_atan_x = INV_ATAN_X, inv_atan_y = INV_ATAN_Y;
   asm volatile("" : "+v"(inv_atan_x), "+v"(inv_atan_y));
-  // Where sample i reads: its two source pixels and their weights.
-  auto locate = [&](int i, const float*& qa, const float*& qc, float& wa, float& wc) {
-    float lx, ly, lz, w0f, h0f;
+  // Where sample i reads: its source pixel in level l0 and, with TWO, the one in level l1, and their weights.
+  // (u, v) of equirectangular.wgsl:68 with the device library's polynomials (equirect_math.h); which pixel a sample
+  // within an ulp of a pixel boundary lands on is not pinned - the reference's own f32 arithmetic does not pin it.
+  auto locate = [&](auto two, int i, const float*& qa, const float*& qc, float& wa, float& wc) {
+    constexpr bool TWO = decltype(two)::value;
+    float lx, ly, lz, kx, cx, ky, cy;
     int l0, l1;
     if constexpr (SPLIT == 1) {
-      const float4 dir = s_table[2 * i], rest = s_table[2 * i + 1];
-      lx = dir.x; ly = dir.y; lz = dir.z; wa = dir.w; wc = rest.x; w0f = rest.y; h0f = rest.z;
-      l0 = samples[i].l0; l1 = samples[i].l1;   // the same in every lane: scalar loads
+      const float4 dir = s_table[2 * i], scale = s_table[2 * i + 1];
+      lx = dir.x; ly = dir.y; lz = dir.z; wa = dir.w; kx = scale.x; cx = scale.y; ky = scale.z; cy = scale.w;
+      if constexpr (TWO) wc = s_wc[i];
+      l0 = samples[i].l0; l1 = TWO ? samples[i].l1 : l0;   // the same in every lane: scalar loads
     } else {
       const PrefilterSample s = samples[i];
       lx = s.lx; ly = s.ly; lz = s.lz; wa = s.wa; wc = s.wc; l0 = s.l0; l1 = s.l1;
-      w0f = (float)max(1, hdr.w >> l0); h0f = (float)max(1, hdr.h >> l0);
+      const float w0f = (float)max(1, hdr.w >> l0), h0f = (float)max(1, hdr.h >> l0);
+      kx = inv_atan_x * w0f; cx = 0.5f * w0f; ky = inv_atan_y * h0f; cy = 0.5f * h0f;
     }
     const V3 L = sample_to_world(T, B, N, lx, ly, lz);
-    const int w0 = max(1, hdr.w >> l0), h0 = max(1, hdr.h >> l0), w1 = max(1, hdr.w >> l1), h1 = max(1, hdr.h >> l1);
-    // (u, v) of equirectangular.wgsl:68.  The two functions are the device library's, evaluated by their
-    // operation-for-operation restatements (equirect_math.h); the few arguments those do not cover - a direction
-    // along the Y axis, a NaN - go to the library itself, the whole wavefront with them.
-    const float yc = fminf(fmaxf(L.y, -1.0f), 1.0f);
-    float theta = atan2_regular(L.z, L.x);
-    if (__builtin_amdgcn_ballot_w64(!equirect_regular(L.z, L.x)) != 0ull) theta = atan2f(L.z, L.x);
-    const float u = fmaf(theta, inv_atan_x, 0.5f), v = fmaf(asin_regular(yc), inv_atan_y, 0.5f);
-    const float tu = u * w0f, tv = v * h0f;
-    int x0, y0, x1, y1;
-    uint32_t i0, i1;   // pixel index within the level
-    if constexpr (SPLIT == 1) { x0 = clamp_to((int)tu, w0 - 1); y0 = clamp_to((int)tv, h0 - 1); }
+    const int w0 = max(1, hdr.w >> l0), h0 = max(1, hdr.h >> l0);
+    const float yc = __builtin_amdgcn_fmed3f(L.y, -1.0f, 1.0f);
+    const float theta = atan2_quick(L.z, L.x), phi = asin_quick(yc);
+    const float tu = fmaf(theta, kx, cx), tv = fmaf(phi, ky, cy);
+    int x0, y0;
+    uint32_t i0;   // pixel index within the level
+    // The angles are at most pi and pi / 2 in magnitude and the scale factors are truncated below 1 / (2 pi) and 1 / pi
+    // (equirectangular.wgsl:2), so the coordinates lie inside [0, size) as they stand (at most 0.99983 and 0.99998
+    // of the size) and a NaN converts to 0: the one-texel-per-lane loop, where every instruction counts, does not clamp.
+    if constexpr (SPLIT == 1 && POW2) { x0 = (int)tu; y0 = (int)tv; }
     else { x0 = max(min((int)tu, w0 - 1), 0); y0 = max(min((int)tv, h0 - 1), 0); }
-    if constexpr (POW2) {
-      // power-of-two source: a level's size is the previous one's half, scaling u by it is exact, and the pixel
-      // of the coarser level (l1 >= l0) is the finer level's pixel shifted down - the same integers as below
-      // (and rows are a shift apart)
-      x1 = x0 >> (l1 - l0); y1 = y0 >> (l1 - l0);
-      i0 = ((uint32_t)y0 << (log2w - l0)) + (uint32_t)x0; i1 = ((uint32_t)y1 << (log2w - l1)) + (uint32_t)x1;
-    } else {
-      x1 = max(min((int)(u * (float)w1), w1 - 1), 0); y1 = max(min((int)(v * (float)h1), h1 - 1), 0);
-      i0 = (uint32_t)y0 * (uint32_t)w0 + (uint32_t)x0; i1 = (uint32_t)y1 * (uint32_t)w1 + (uint32_t)x1;
-    }
     // (the level's start is added to the pointer, where it is scalar arithmetic, not to the per-lane index)
+    if constexpr (POW2) i0 = ((uint32_t)y0 << (log2w - l0)) + (uint32_t)x0;
+    else i0 = (uint32_t)y0 * (uint32_t)w0 + (uint32_t)x0;
     qa = hdr.rgb + 3 * (size_t)hdr.off[l0] + 3 * (size_t)i0;
-    qc = hdr.rgb + 3 * (size_t)hdr.off[l1] + 3 * (size_t)i1;
+    if constexpr (TWO) {
+      const int w1 = max(1, hdr.w >> l1), h1 = max(1, hdr.h >> l1);
+      int x1, y1;
+      uint32_t i1;
+      if constexpr (POW2) {
+        // power-of-two source: a level's size is the previous one's half, scaling u by it is exact, and the pixel
+        // of the coarser level (l1 >= l0) is the finer level's pixel shifted down - the same integers as below
+        // (and rows are a shift apart)
+        x1 = x0 >> (l1 - l0); y1 = y0 >> (l1 - l0);
+        i1 = ((uint32_t)y1 << (log2w - l1)) + (uint32_t)x1;
+      } else {
+        const float u = fmaf(theta, inv_atan_x, 0.5f), v = fmaf(phi, inv_atan_y, 0.5f);
+        x1 = max(min((int)(u * (float)w1), w1 - 1), 0); y1 = max(min((int)(v * (float)h1), h1 - 1), 0);
+        i1 = (uint32_t)y1 * (uint32_t)w1 + (uint32_t)x1;
+      }
+      qc = hdr.rgb + 3 * (size_t)hdr.off[l1] + 3 * (size_t)i1;
+    }
   };
   // Several samples at a time: the samples' source pixels are located first and their 12-byte loads issued together,
-  // so that a wavefront has several times the requests in flight (the kernel's time is the latency of the requests that
-  // leave L1, at full occupancy); the sums take the samples in their order.  2048^2 x 10 levels: 16.9 ms one sample at a
-  // time, 15.7 / 15.15 / 15.5 / 17.1 ms in groups of 2 / 3 / 4 / 6 (45 / 60 / 66 / 66 registers: beyond 64 a SIMD holds 7 waves;
-  // groups of 4 and 5 held to 64 registers: 15.6 and 15.7 ms).
+  // so that a wavefront has several times the requests in flight; the sums take the samples in the table's order.
+  // 2048^2 x 10 levels with two-pixel samples only: 16.9 ms one sample at a time, 15.7 / 15.15 / 15.5 / 17.1 ms in groups
+  // of 2 / 3 / 4 / 6 (45 / 60 / 66 / 66 registers: beyond 64 a SIMD holds 7 waves).
 #ifndef PBR_PREFILTER_GROUP
 #define PBR_PREFILTER_GROUP 3
 #endif
   constexpr int kGroup = PBR_PREFILTER_GROUP;
+  const std::true_type two_levels;
+  const std::false_type one_level;
   int i = sub;
+  if constexpr (SPLIT == 1) {
+    // the table's leading samples read one source level: one pixel, one weight
+    for (; i + (kGroup - 1) < n_single; i += kGroup) {
+      const float *qa[kGroup], *qc;
+      float wa[kGroup], wc;
+      V3 a[kGroup];
+#pragma unroll
+      for (int k = 0; k < kGroup; ++k) locate(one_level, i + k, qa[k], qc, wa[k], wc);
+#pragma unroll
+      for (int k = 0; k < kGroup; ++k) a[k] = v3(qa[k][0], qa[k][1], qa[k][2]);   // one 12-byte load each
+#pragma unroll
+      for (int k = 0; k < kGroup; ++k) { r = fmaf(a[k].x, wa[k], r); g = fmaf(a[k].y, wa[k], g); b = fmaf(a[k].z, wa[k], b); }
+    }
+    for (; i < n_single; ++i) {
+      const float *qa, *qc;
+      float wa, wc;
+      locate(one_level, i, qa, qc, wa, wc);
+      r = fmaf(qa[0], wa, r); g = fmaf(qa[1], wa, g); b = fmaf(qa[2], wa, b);
+    }
+  }
   for (; i + (kGroup - 1) * SPLIT < n_samples; i += kGroup * SPLIT) {
     const float *qa[kGroup], *qc[kGroup];
     float wa[kGroup], wc[kGroup];
     V3 a[kGroup], c[kGroup];
 #pragma unroll
-    for (int k = 0; k < kGroup; ++k) locate(i + k * SPLIT, qa[k], qc[k], wa[k], wc[k]);
+    for (int k = 0; k < kGroup; ++k) locate(two_levels, i + k * SPLIT, qa[k], qc[k], wa[k], wc[k]);
 #pragma unroll
     for (int k = 0; k < kGroup; ++k) { a[k] = v3(qa[k][0], qa[k][1], qa[k][2]); c[k] = v3(qc[k][0], qc[k][1], qc[k][2]); }   // one 12-byte load each
 #pragma unroll
@@ -311,7 +346,7 @@ prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, i
   for (; i < n_samples; i += SPLIT) {
     const float *qa, *qc;
     float wa, wc;
-    locate(i, qa, qc, wa, wc);
+    locate(two_levels, i, qa, qc, wa, wc);
     const V3 a = v3(qa[0], qa[1], qa[2]), c = v3(qc[0], qc[1], qc[2]);
     r += a.x * wa + c.x * wc; g += a.y * wa + c.y * wc; b += a.z * wa + c.z * wc;
   }
@@ -401,7 +436,7 @@ void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int 
   hipLaunchKernelGGL(irradiance_kernel, dim3(6 * size * size), dim3(256), 0, s, hdr, tables, n_phi, n_theta, out, size);
 }
 
-void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, float total_weight,
+void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, int n_single, float total_weight,
                       float4* out_level, int level_size, int64_t first, int64_t count) {
   if (count <= 0) return;
   const bool pow2 = (hdr.w & (hdr.w - 1)) == 0 && (hdr.h & (hdr.h - 1)) == 0 && hdr.w >= hdr.h;
@@ -417,22 +452,22 @@ void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* sam
     const int per_group = wide ? kPrefilterWideThreads : kPrefilterNarrowThreads;
     const dim3 grid((unsigned)((threads + per_group - 1) / per_group)), block(per_group);
 #define PBR_LAUNCH_PREFILTER(POW2_, THREADS_) \
-    hipLaunchKernelGGL((prefilter_kernel<1, POW2_, THREADS_>), grid, block, 0, s, hdr, samples, n_samples, total_weight, out_level, level_size, (long long)first, \
+    hipLaunchKernelGGL((prefilter_kernel<1, POW2_, THREADS_>), grid, block, 0, s, hdr, samples, n_samples, n_single, total_weight, out_level, level_size, (long long)first, \
                        (long long)count)
     if (pow2) { if (wide) PBR_LAUNCH_PREFILTER(true, kPrefilterWideThreads); else PBR_LAUNCH_PREFILTER(true, kPrefilterNarrowThreads); }
     else { if (wide) PBR_LAUNCH_PREFILTER(false, kPrefilterWideThreads); else PBR_LAUNCH_PREFILTER(false, kPrefilterNarrowThreads); }
 #undef PBR_LAUNCH_PREFILTER
   } else if (level_texels >= (1 << 14)) {
     long long threads = count * 8;
-    if (pow2) hipLaunchKernelGGL((prefilter_kernel<8, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+    if (pow2) hipLaunchKernelGGL((prefilter_kernel<8, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, 0, total_weight,
                                  out_level, level_size, (long long)first, (long long)count);
-    else hipLaunchKernelGGL((prefilter_kernel<8, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+    else hipLaunchKernelGGL((prefilter_kernel<8, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, 0, total_weight,
                             out_level, level_size, (long long)first, (long long)count);
   } else {
     long long threads = count * 64;
-    if (pow2) hipLaunchKernelGGL((prefilter_kernel<64, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+    if (pow2) hipLaunchKernelGGL((prefilter_kernel<64, true>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, 0, total_weight,
                                  out_level, level_size, (long long)first, (long long)count);
-    else hipLaunchKernelGGL((prefilter_kernel<64, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, total_weight,
+    else hipLaunchKernelGGL((prefilter_kernel<64, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, 0, total_weight,
                             out_level, level_size, (long long)first, (long long)count);
   }
 }

@@ -121,14 +121,19 @@ uint32_t radical_inverse(uint32_t bits) {
 // texel.  With N = R = V the half vector, N.L, the pdf and therefore the source mip are functions
 // of the sample index and the roughness only; they are tabulated in the texel's tangent frame
 // (tangent, bitangent, N) and samples with N.L <= 0 are dropped.
-int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out, float* total_weight) {
+// The samples whose two source levels coincide (a level of detail below the finest source level or above the coarsest:
+// both clamp to the same level, the blend of a pixel with itself) come first in the table, *n_single of them, with
+// the whole weight N.L in wa: the kernel fetches one pixel for them instead of two.  Half the samples of the
+// smoothest filtered level of a large map, three quarters of the whole work, are of this kind.
+int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out, float* total_weight, int* n_single) {
   const float PI = 3.14159265359f;
   const uint32_t N = PBR_PREFILTER_SAMPLES;
   if (roughness == 0.0f) {
     // every sample is H = L = N with weight 1 and source level 0: one entry reproduces the sum exactly
-    PrefilterSample s = {0.0f, 0.0f, 1.0f, 0.0f, 0, std::min(1, src_levels - 1), 1.0f, 0.0f};   // weights (1 - 0) * 1 and 0 * 1
+    PrefilterSample s = {0.0f, 0.0f, 1.0f, 0.0f, 0, 0, 1.0f, 0.0f};
     out[0] = s;
     *total_weight = 1.0f;
+    *n_single = 1;
     return 1;
   }
   int n = 0;
@@ -163,29 +168,34 @@ int build_prefilter_table(float roughness, int src_levels, PrefilterSample* out,
     s.l0 = std::min(std::max(m0, 0), src_levels - 1);       // a level outside the chain is clamped into it
     s.l1 = std::min(std::max(m0 + 1, 0), src_levels - 1);
     s.wa = (1.0f - s.mix) * s.lz; s.wc = s.mix * s.lz;   // this file is built without FMA contraction: the kernel's former two roundings each
+    if (s.l0 == s.l1) { s.wa = s.lz; s.wc = 0.0f; }
     out[n++] = s;
     total += ndotl;
   }
   *total_weight = total;
+  *n_single = (int)(std::stable_partition(out, out + n, [](const PrefilterSample& s) { return s.l0 == s.l1; }) - out);
   return n;
 }
 
 // renderer.ts:1559: roughness = mip / (maxMipLevels - 1) stored as f32; a single level gets 0
 float prefilter_roughness(int level, int mips) { return mips > 1 ? (float)((double)level / (double)(mips - 1)) : 0.0f; }
 
-// Cost model of the prefilter, for cutting it into shards of equal duration.  A texel of level m costs the samples
-// the level's table keeps (those with N.L > 0; one at roughness 0) plus a constant for the work a texel does whatever
-// its sample count (direction, tangent frame, the 16-byte store) - times what a sample costs there, which is the
-// price of its two source-pixel gathers and was measured on MI355X (2048^2 x 10 levels from a 4096 x 2048 source,
-// every face of every level filtered on its own, scripts/gpu_prefilter_shards.py):
-//   * the +-Y faces look at the pole rows of the equirect image, where a block of neighbouring directions is
-//     stretched over many more pixels of a row (more cache lines per wavefront load): 1.41 x the other faces at
-//     the smoothest filtered level, whose samples read the finest source levels, 1.67 x at the next, 1.05 x beyond;
-//   * rougher levels scatter their samples wider and are smaller launches: 1.24 x and 1.37 x per sample.
-// (Re-measured with the kernel that takes its samples three at a time; the kernel before it had 1.6 / 1.4 and 1.32.)
+// Cost model of the prefilter, for cutting it into shards of equal duration: picoseconds per texel on one MI355X,
+// from timings of every face of every level of the 2048^2 x 10 map filtered from a 4096 x 2048 source
+// (scripts/gpu_prefilter_shards.py, profiles/r03_prefilter_shards.json).  A texel costs the samples its level's table
+// keeps (those with N.L > 0; one at roughness 0) plus a constant for the work a texel does whatever its sample
+// count, times what a sample costs there:
+//   * 1.22 ns per thousand samples on the side faces of the smoothest filtered level (the kernel is bound by
+//     vector-instruction issue there, and half that level's samples read one source level instead of two);
+//   * the +-Y faces look at the pole rows of the equirect image, where a block of neighbouring directions is stretched
+//     over many more pixels of a row (more cache lines per wavefront load): 1.45 x at the smoothest filtered level,
+//     1.74 x at the next; rougher levels scatter their samples wider on every face: 1.47 x, then 1.6 x per sample;
+//   * levels of fewer than 2^18 texels spread a texel's samples over 8 or 64 lanes (launch_prefilter) and no longer
+//     fill the chip: 1.85 x and 1.6 x per sample;
+//   * every level is a launch of its own with a floor of 8.5 us, spread here over the level's texels.
 // Only the balance of the shards depends on these numbers, never a result.
 constexpr uint64_t PREFILTER_TEXEL_OVERHEAD = 8;
-struct PrefilterCost { int kept[PBR_MAX_LEVELS]; uint64_t per_texel[PBR_MAX_LEVELS][6]; };
+struct PrefilterCost { int kept[PBR_MAX_LEVELS]; };
 void prefilter_costs(int mips, PrefilterCost* pc) {
   // (the tables take a fraction of a millisecond of host arithmetic; a caller that filters map after map with one level
   // count would otherwise pay it ahead of every call's first launch)
@@ -195,14 +205,20 @@ void prefilter_costs(int mips, PrefilterCost* pc) {
   std::vector<PrefilterSample> table(PBR_PREFILTER_SAMPLES);
   for (int m = 0; m < mips; ++m) {
     float weight;
-    const float roughness = prefilter_roughness(m, mips);
-    const int n = build_prefilter_table(roughness, PBR_MAX_LEVELS, table.data(), &weight);   // the count does not depend on the source's level count
-    pc->kept[m] = n;
-    const uint64_t side = roughness == 0.0f ? 100 : roughness <= 0.17f ? 100 : roughness <= 0.28f ? 124 : 137;   // per sample, in hundredths
-    const uint64_t pole = roughness == 0.0f ? 100 : roughness <= 0.17f ? 141 : roughness <= 0.28f ? 207 : 144;
-    for (int f = 0; f < 6; ++f) pc->per_texel[m][f] = ((uint64_t)n + PREFILTER_TEXEL_OVERHEAD) * ((f == 2 || f == 3) ? pole : side);
+    int single;
+    pc->kept[m] = build_prefilter_table(prefilter_roughness(m, mips), PBR_MAX_LEVELS, table.data(), &weight, &single);   // the count does not depend on the source's level count
   }
   cached = *pc; cached_mips = mips;
+}
+// picoseconds per texel of face f of level m
+uint64_t prefilter_texel_cost(const PrefilterCost& pc, int size, int mips, int m, int f) {
+  const float roughness = prefilter_roughness(m, mips);
+  const uint64_t s = (uint64_t)std::max(1, size >> m), level_texels = 6 * s * s;
+  if (roughness == 0.0f) return 10 + 8500000 / level_texels;   // a copy of the source pixel
+  const bool pole = f == 2 || f == 3;
+  const uint64_t scatter = roughness <= 0.17f ? (pole ? 145 : 100) : roughness <= 0.28f ? (pole ? 255 : 147) : (pole ? 170 : 160);   // hundredths
+  const uint64_t shape = level_texels >= (1u << 18) ? 100 : level_texels >= (1u << 14) ? 185 : 160;
+  return ((uint64_t)pc.kept[m] + PREFILTER_TEXEL_OVERHEAD) * 122 * scatter * shape / 1000000 + 8500000 / level_texels;
 }
 
 // A level whose texels take less time to filter than to send is not worth sharding: every shard filters it for itself
@@ -231,7 +247,7 @@ void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
   for (int m = 0; m < mips; ++m) {
     const uint64_t s = (uint64_t)std::max(1, size >> m);
     if (m < first_level) replicated_texels += 6 * s * s;
-    else for (int f = 0; f < 6; ++f) total_cost += s * s * pc.per_texel[m][f];
+    else for (int f = 0; f < 6; ++f) total_cost += s * s * prefilter_texel_cost(pc, size, mips, m, f);
     total_texels += 6 * s * s;
   }
   cuts[0] = replicated_texels; cuts[n] = total_texels;
@@ -242,8 +258,8 @@ void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
     for (int m = first_level; m < mips && !placed; ++m) {
       const uint64_t s = (uint64_t)std::max(1, size >> m), face_texels = s * s;
       for (int f = 0; f < 6 && !placed; ++f) {
-        const uint64_t c = face_texels * pc.per_texel[m][f];
-        if (before_cost + c > target) { cuts[k] = before_texels + (target - before_cost) / pc.per_texel[m][f]; placed = true; }
+        const uint64_t per_texel = prefilter_texel_cost(pc, size, mips, m, f), c = face_texels * per_texel;
+        if (before_cost + c > target) { cuts[k] = before_texels + (target - before_cost) / per_texel; placed = true; }
         else { before_cost += c; before_texels += face_texels; }
       }
     }
@@ -341,6 +357,7 @@ struct PbrContextPrivate {
   int prefilter_tables_for = -1;          // mips the cached sample tables were built for
   int prefilter_src_levels = -1;
   int table_count[PBR_MAX_LEVELS] = {};
+  int table_single[PBR_MAX_LEVELS] = {};   // leading samples of each table that read one source level
   float table_weight[PBR_MAX_LEVELS] = {};
   uint32_t frames_drawn = 0;
   // Bordered copies of the cube maps for the resolve: every face carries the adjoining texels of its
@@ -1032,7 +1049,7 @@ static int prefilter_texel_range(PbrContext* c, int32_t size, int32_t mips, int3
     std::vector<PrefilterSample> host((size_t)PBR_PREFILTER_SAMPLES * mips);
     for (int m = 0; m < mips; ++m) {
       const float roughness = prefilter_roughness(m, mips);
-      pr->table_count[m] = build_prefilter_table(roughness, c->hdr.levels, host.data() + (size_t)m * PBR_PREFILTER_SAMPLES, &pr->table_weight[m]);
+      pr->table_count[m] = build_prefilter_table(roughness, c->hdr.levels, host.data() + (size_t)m * PBR_PREFILTER_SAMPLES, &pr->table_weight[m], &pr->table_single[m]);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(c->d_samples, host.data(), host.size() * sizeof(PrefilterSample), hipMemcpyHostToDevice));
@@ -1053,7 +1070,7 @@ static int prefilter_texel_range(PbrContext* c, int32_t size, int32_t mips, int3
     // the levels in front of the shards' ranges are filtered whole by every shard (prefilter_cuts)
     const size_t a = hi <= (size_t)replicated ? lo : std::max(lo, (size_t)begin), b = hi <= (size_t)replicated ? hi : std::min(hi, (size_t)end);
     if (a >= b) continue;
-    launch_prefilter(c->stream, c->hdr, c->d_samples + (size_t)m * PBR_PREFILTER_SAMPLES, pr->table_count[m], pr->table_weight[m],
+    launch_prefilter(c->stream, c->hdr, c->d_samples + (size_t)m * PBR_PREFILTER_SAMPLES, pr->table_count[m], pr->table_single[m], pr->table_weight[m],
                      c->d_pre + lo, (int)s, (int64_t)(a - lo), (int64_t)(b - a));
   }
   pr->pre_b.dirty = true;

@@ -183,7 +183,8 @@ void launch_build_mips_rgba8(hipStream_t s, const uint32_t* linear_level0, uint3
 void launch_drop_alpha(hipStream_t s, const float4* rgba, float* rgb, size_t texels);
 void launch_equirect_to_cube(hipStream_t s, DevEquirect hdr, float4* out, int size);
 void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int n_phi, int n_theta, float4* out, int size);
-void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, float inv_weight,
+// n_single: the leading samples of the table that read one source level (see build_prefilter_table)
+void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, int n_single, float inv_weight,
                       float4* out_level, int level_size, int64_t first, int64_t count);
 void launch_brdf_lut(hipStream_t s, uint16_t* out, int size);
 

@@ -20,7 +20,7 @@ def device_bytes_tensor(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
-def prefilter_sharded(renderer, size, mips, rank=None, world=None, device=None, how="collective"):
+def prefilter_sharded(renderer, size, mips, rank=None, world=None, device=None, how="p2p"):
     """Each rank filters the levels that are cheaper to filter than to send (level 0) plus its own range of the
     others, then one exchange of those ranges makes the whole map resident on every GPU (so every GPU can shade).
     Returns the bytes this rank contributed to the exchange; the map lives in the renderer's context."""
@@ -61,15 +61,16 @@ def release_staging():
     _staging.clear()
 
 
-def all_gather_ranges(whole, byte_ranges, rank, how="collective"):
+def all_gather_ranges(whole, byte_ranges, rank, how="p2p"):
     """In-place all-gather of unequal contiguous byte ranges of `whole` (a 1-D uint8 tensor that
     every rank holds, each with its own range filled in).  Returns the bytes this rank contributed.
 
-    how="collective": one all_gather_into_tensor (RCCL's all-gather drives all of a GPU's xGMI links at once) of
-    chunks as large as the largest range; the ranges are cuts of equal cost through levels of similar cost per
-    byte, so the padding is small (a fifth at eight ranks of the 2048^2 x 10 map), and the buffers are kept.
-    how="p2p": every rank sends its range straight from `whole` into every peer's `whole` (one batch of
-    isend / irecv, seven direct links on an MI355X node): nothing padded, nothing staged, nothing copied."""
+    how="p2p" (the default): every rank sends its range straight from `whole` into every peer's `whole`, one batch of
+    isend / irecv.  The GPUs of an MI355X node are fully connected, seven direct xGMI links each, so a rank's seven
+    sends each have a link of their own; nothing is padded, staged or copied.
+    how="collective": one all_gather_into_tensor of chunks as large as the largest range.  The ranges are cuts of
+    equal cost, not of equal size (a third above the mean at eight ranks of the 2048^2 x 10 map), and pass through
+    staging buffers that are allocated once and kept."""
     world = len(byte_ranges)
     b, e = byte_ranges[rank]
     if how == "p2p":

@@ -58,7 +58,7 @@ def prefilter_replicated_texels(size, mips, world):
     return prefilter_cuts(size, mips, world)[0]
 
 
-def prefilter_exchange_bytes(size, mips, world, how="collective"):
+def prefilter_exchange_bytes(size, mips, world, how="p2p"):
     """Bytes every rank contributes to the exchange of the shards (16 per texel): its own range when the ranges go
     peer to peer, the largest range when one all-gather of equal chunks carries them."""
     cuts = prefilter_cuts(size, mips, world)
