@@ -1,8 +1,8 @@
-"""Builds profiles/r02_valu.json: per frame kernel the counted vector instructions, L1 tag lookups and busy cycles of
+"""Builds profiles/r0N_valu.json: per frame kernel the counted vector instructions, L1 tag lookups and busy cycles of
 the texture-address units per launch (from the summary scripts/gpu_pmc_frame.sh leaves), and the mean issue cost of
 the kernel's vector instructions (its compiled instruction mix priced by scripts/isa_issue_cost.py).
 
-    python scripts/valu_profile.py gpurun_out/<prefix>/summary.txt > profiles/r02_valu.json
+    python scripts/valu_profile.py gpurun_out/<prefix>/summary.txt > profiles/r0N_valu.json
 """
 import collections
 import json

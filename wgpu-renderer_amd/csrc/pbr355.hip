@@ -270,13 +270,18 @@ void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
 // The skybox pass unprojects every pixel centre: x_ndc = (x + 0.5) 2 / W - 1, y_ndc = 1 - (y + 0.5) 2 / H, then
 // inv_view_proj * (x_ndc, y_ndc, 1, 1) (skybox.wgsl:13-27).  That is affine in the pixel coordinates; the three vectors
 // are worked out here in double precision and rounded once.
-void sky_affine(const float* m, int W, int H, FrameParams& fp) {
+// Returns false when a coefficient is not finite: the skybox lookups do not clamp their texel coordinates (see
+// cube_foot_pair), which is safe for every finite unprojection and for none that is not.
+bool sky_affine(const float* m, int W, int H, FrameParams& fp) {
+  bool finite = true;
   for (int r = 0; r < 4; ++r) {
     const double c0 = m[r], c1 = m[4 + r], c2 = m[8 + r], c3 = m[12 + r];
     fp.sky_a[r] = (float)(c0 * (1.0 / W - 1.0) + c1 * (1.0 - 1.0 / H) + c2 + c3);
     fp.sky_bx[r] = (float)(c0 * 2.0 / W);
     fp.sky_by[r] = (float)(-c1 * 2.0 / H);
+    finite = finite && std::isfinite(fp.sky_a[r]) && std::isfinite(fp.sky_bx[r]) && std::isfinite(fp.sky_by[r]);
   }
+  return finite;
 }
 
 // the context that owns the scene (mesh, textures, IBL maps): the context itself, or the one it was forked from
@@ -580,7 +585,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   fp.has_instance_mats = a->has_instance_mats ? 1 : 0;
   fp.msaa = msaa ? 1 : 0;
   fp.two_over_w = 2.0f / (float)W; fp.two_over_h = 2.0f / (float)H;
-  sky_affine(u->inv_view_proj, W, H, fp);
+  if (!sky_affine(u->inv_view_proj, W, H, fp)) return fail(c, PBR_E_ARG, "the inverse view-projection matrix (skybox uniform, renderer.ts:1864-1867) is not finite");
   const FrameParams& dp = fp;
   hipStream_t s = c->stream;
 
@@ -1286,7 +1291,7 @@ int pbr_draw_views_device(PbrContext* c, int32_t n_views, const PbrFrameUniforms
     fp.has_instance_mats = a->has_instance_mats ? 1 : 0;
     fp.msaa = 0;
     fp.two_over_w = 2.0f / (float)W; fp.two_over_h = 2.0f / (float)H;
-    sky_affine(u[v].inv_view_proj, W, H, fp);
+    if (!sky_affine(u[v].inv_view_proj, W, H, fp)) return fail(c, PBR_E_ARG, "the inverse view-projection matrix of view %d (skybox uniform, renderer.ts:1864-1867) is not finite", v);
     uint32_t* counters = w->d_counters + 8 * wpr->counter_set;
     uint32_t* next_counters = w->d_counters + 8 * (1 - wpr->counter_set);
     wpr->counter_set = 1 - wpr->counter_set;

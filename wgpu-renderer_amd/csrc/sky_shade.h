@@ -90,13 +90,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct CubeFootPair { uint32_t o[2]; uint32_t m; f2 w[4]; };   // element k of each weight belongs to the pixel with offset o[k]
 
-// min(max(x, -1), top) for a wave-uniform top >= -1, as the single median instruction it is
-PBR_DEV int clamp_from_minus_one(int x, int top) {
-  int r;
-  asm("v_med3_i32 %0, %1, -1, %2" : "=v"(r) : "v"(x), "s"(top));
-  return r;
-}
-
 // cube_foot on level 0 for two lookups at once (faces and face coordinates given per element).
 PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int face1, f2 sc, f2 tc, f2 rc) {
 #pragma clang fp contract(fast)
@@ -105,18 +98,18 @@ PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int f
   const float fn = (float)n;
   const f2 ima = {rcp_fast(fabsf(rc.x)), rcp_fast(fabsf(rc.y))};
   const f2 s = 0.5f * (sc * ima) + 0.5f, t = 0.5f * (tc * ima) + 0.5f;
-  const f2 tu = s * fn - 0.5f, tv = t * fn - 0.5f;
-  const f2 fu = {floorf(tu.x), floorf(tu.y)}, fv = {floorf(tv.x), floorf(tv.y)};
-  const f2 a = tu - fu, b = tv - fv;
+  // Texel coordinates counted from the border texel: tu + 1 = s n + 1/2 lies in [1/2, n + 1/2], so its integer part
+  // (a plain conversion: nothing is negative) is the column in the bordered face and its fraction the blend weight.
+  // |sc| and |tc| never exceed |rc| (rc is the component the face was selected by), and the host refuses a frame
+  // whose unprojection is not finite, so the coordinates need no clamp; a NaN (a zero direction) converts to column 0.
+  const f2 tu = s * fn + 0.5f, tv = t * fn + 0.5f;
+  const f2 a = {__builtin_amdgcn_fractf(tu.x), __builtin_amdgcn_fractf(tu.y)}, b = {__builtin_amdgcn_fractf(tv.x), __builtin_amdgcn_fractf(tv.y)};
   const f2 oma = 1.0f - a, omb = 1.0f - b;
   f.w[0] = oma * omb; f.w[1] = a * omb; f.w[2] = oma * b; f.w[3] = a * b;
-  // (one v_med3_i32 each; the coordinates are in range by construction, the clamp only keeps a NaN or an overflow inside the map)
-  const int top = __builtin_amdgcn_readfirstlane(n - 1);   // the same in every lane
-  const int i0 = clamp_from_minus_one((int)fu.x, top), j0 = clamp_from_minus_one((int)fv.x, top);
-  const int i1 = clamp_from_minus_one((int)fu.y, top), j1 = clamp_from_minus_one((int)fv.y, top);
+  const int i0 = (int)tu.x, j0 = (int)tv.x, i1 = (int)tu.y, j1 = (int)tv.y;
   // texel index with 24-bit multiply-adds (face * m + row and m are far below 2^24 for any cube the library accepts)
-  f.o[0] = bordered.off[0] + __umul24(__umul24((uint32_t)face0, (uint32_t)m) + (uint32_t)(j0 + 1), (uint32_t)m) + (uint32_t)(i0 + 1);
-  f.o[1] = bordered.off[0] + __umul24(__umul24((uint32_t)face1, (uint32_t)m) + (uint32_t)(j1 + 1), (uint32_t)m) + (uint32_t)(i1 + 1);
+  f.o[0] = bordered.off[0] + __umul24(__umul24((uint32_t)face0, (uint32_t)m) + (uint32_t)j0, (uint32_t)m) + (uint32_t)i0;
+  f.o[1] = bordered.off[0] + __umul24(__umul24((uint32_t)face1, (uint32_t)m) + (uint32_t)j1, (uint32_t)m) + (uint32_t)i1;
   f.m = (uint32_t)m;
   return f;
 }
