@@ -612,7 +612,8 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
     """Second headline figure: the IBL GGX prefilter at 2048^2 x 10 mips x 1024 samples.  One GPU filters the whole map;
     with several ranks each filters its shard (equal cost, not equal texel counts) and one all-gather (RCCL) makes the
     map whole on every GPU."""
-    world, rank, local_rank, use_dist, dev, _ = ctxinfo
+    world, rank, local_rank, use_dist, dev, frame_streams = ctxinfo
+    lane_stream = frame_streams[0]           # the torch stream the first context runs on (run_orbit)
     import importlib
     parallel = importlib.import_module(pkg.__name__ + ".parallel")
     sharding = importlib.import_module(pkg.__name__ + ".sharding")
@@ -629,7 +630,8 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
             if not use_dist:
                 pkg._lib.check(r._ctx, lib.pbr_ibl_prefilter(r._ctx, size, mips, 1024, 0, 1))
             else:
-                sent[0] = parallel.prefilter_sharded(r, size, mips, rank, world, dev, how=how)
+                sent[0] = parallel.prefilter_sharded(r, size, mips, rank, world, dev, how=how, stream=lane_stream, comm_stream=frame_streams[1] if len(frame_streams) > 1 else None,
+                                                         rehearse=True)
             torch.cuda.synchronize(dev)
         once()                                   # allocate + warm (the exchange's staging buffers too: they are kept)
         ms = timed_region(torch, dist, use_dist, dev, 1, lambda i: once()) * 1e3
@@ -642,7 +644,7 @@ def run_prefilter(args, pkg, torch, dist, ctxinfo, r, result):
             info["exchange"] = "none (one rank)" if world == 1 else (f"every rank filters the first {cuts[0]} texels (roughness 0) for itself; the other {(texels - cuts[0]) * 16 / 1e6:.0f} MB of the "
                                 f"{texels * 16 / 1e6:.0f} MB map are cut by cost and exchanged ("
                                 + ("one all-gather of equal chunks, staging kept between calls" if how != "p2p" else "peer to peer, in place")
-                                + "), included in ms")
+                                + ", while the first texels are being filtered), included in ms")
         kept = sharding.prefilter_kept_samples(mips)
         executed = sum(k * t for k, t in zip(kept, level_texels))
         info.update({"ms": ms,

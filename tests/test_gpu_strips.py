@@ -1,4 +1,7 @@
-"""The screen-strip split across ranks: two processes (both on the one GPU of the test box) each upload the instanced
+"""The two exchanges of the multi-GPU drivers with more than one rank on the one GPU of the test box (gloo, since two ranks
+cannot share one GPU under RCCL; the data crosses on the host).
+
+The screen-strip split across ranks: two processes (both on the one GPU of the test box) each upload the instanced
 scene, render their even-aligned band through the C ABI and gather the bands to rank 0 with the same
 parallel.gather_strips the benchmark's strips mode uses (gloo here, since two ranks cannot share one GPU under RCCL):
 rank 0's gathered frame must equal the frame one process renders alone, byte for byte."""
@@ -74,3 +77,60 @@ def test_gathered_strips_equal_the_single_process_frame(world):
         assert ok, (rank, ok)
         if rank == 0:
             assert lit > W * H // 2
+
+
+def _prefilter_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import ctypes as C
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+    lib = pkg._lib
+    from wgpu_renderer_amd import parallel, sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        size, mips = 128, 5
+        hdr = pkg.synthetic_sky(2048, 1024)
+        r = pkg.Renderer(width=64, height=64, hdr=hdr)
+        r._open()
+        data = np.ascontiguousarray(hdr.data, dtype=np.float32)
+        lib.check(r._ctx, r._lib.pbr_upload_hdr(r._ctx, data.ctypes.data_as(C.c_void_p), hdr.width, hdr.height))
+        # what parallel.prefilter_sharded does on the device: the rank's own range, and the leading texels nobody sends
+        cuts = sharding.prefilter_cuts(size, mips, world)
+        lib.check(r._ctx, r._lib.pbr_ibl_prefilter_texels(r._ctx, size, mips, 1024, cuts[rank], cuts[rank + 1] - cuts[rank]))
+        lib.check(r._ctx, r._lib.pbr_ibl_prefilter_texels(r._ctx, size, mips, 1024, 0, cuts[0]))
+        r.synchronize()
+        mine = np.concatenate([r.download_map(lib.MAP_PREFILTER, m).reshape(-1) for m in range(mips)])
+        whole = torch.from_numpy(mine.view(np.uint8).copy())
+        ranges = [(16 * b, 16 * e) for b, e in zip(cuts[:-1], cuts[1:])]
+        # a rank holds nothing of the other ranks' ranges before the exchange
+        other = [whole[b:e] for k, (b, e) in enumerate(ranges) if k != rank and e > b]
+        nothing_yet = all(not bool(t.any()) for t in other)
+        sent = parallel.all_gather_ranges(whole, ranges, rank, how="p2p")
+        lib.check(r._ctx, r._lib.pbr_ibl_prefilter(r._ctx, size, mips, 1024, 0, 1))      # the whole map, by this process alone
+        alone = np.concatenate([r.download_map(lib.MAP_PREFILTER, m).reshape(-1) for m in range(mips)]).view(np.uint8)
+        q.put((rank, nothing_yet, bool((whole.numpy() == alone).all()), sent == ranges[rank][1] - ranges[rank][0], cuts[0] == 6 * size * size))
+        r.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_prefilter_equals_the_single_process_map(world):
+    """Every rank filters its own range of levels 1.. and all of level 0, the ranges are exchanged peer to peer, and
+    every rank then holds the bytes one process computes alone."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prefilter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for res in results:
+        assert all(res[1:]), res

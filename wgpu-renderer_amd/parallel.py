@@ -20,28 +20,65 @@ def device_bytes_tensor(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
-def prefilter_sharded(renderer, size, mips, rank=None, world=None, device=None, how="p2p"):
-    """Each rank filters the levels that are cheaper to filter than to send (level 0) plus its own range of the
-    others, then one exchange of those ranges makes the whole map resident on every GPU (so every GPU can shade).
-    Returns the bytes this rank contributed to the exchange; the map lives in the renderer's context."""
+def prefilter_sharded(renderer, size, mips, rank=None, world=None, device=None, how="p2p", stream=None, comm_stream=None, rehearse=False):
+    """Each rank filters its own range of the levels that are worth sharding, then the ranges are exchanged so that the
+    whole map is resident on every GPU (every GPU can shade), and the levels that are cheaper to filter than to send
+    (level 0) are filtered by every rank for itself.  With `stream` - the torch stream the renderer's context runs on
+    (Renderer.set_stream) - the exchange runs on a second stream while level 0 is being filtered; without it the steps
+    follow each other (`comm_stream`: the second stream, else one is created and kept).  `rehearse` takes a single rank
+    through the same steps (its range is then the whole map and the exchange has no peer).  Returns the bytes this rank
+    contributed to the exchange; the map lives in the renderer's context."""
     rank = dist.get_rank() if rank is None else rank
     world = dist.get_world_size() if world is None else world
     lib = renderer._lib
-    _lib.check(renderer._ctx, lib.pbr_ibl_prefilter(renderer._ctx, size, mips, 1024, rank, world))
-    if world == 1:
+    ctx = renderer._ctx
+    if world == 1 and not rehearse:
+        _lib.check(ctx, lib.pbr_ibl_prefilter(ctx, size, mips, 1024, 0, 1))
         return 0
+    cuts = sharding.prefilter_cuts(size, mips, world)
+    own_first, own_end = cuts[rank], cuts[rank + 1]
+    # this rank's own range first (the call also allocates the map when its size changed) ...
+    _lib.check(ctx, lib.pbr_ibl_prefilter_texels(ctx, size, mips, 1024, own_first, own_end - own_first))
     ptr, total = C.c_void_p(), C.c_size_t()
-    _lib.check(renderer._ctx, lib.pbr_ibl_device_ptr(renderer._ctx, _lib.MAP_PREFILTER, C.byref(ptr), C.byref(total)))
+    _lib.check(ctx, lib.pbr_ibl_device_ptr(ctx, _lib.MAP_PREFILTER, C.byref(ptr), C.byref(total)))
     device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
     whole = device_bytes_tensor(ptr.value, total.value, device)
-    renderer.synchronize()
-    sent = all_gather_ranges(whole, [tuple(16 * t for t in sharding.prefilter_shard_texels(size, mips, r, world)) for r in range(world)], rank, how=how)
-    # the gather ran on torch's stream and wrote through the library's pointer: finish it before the
-    # renderer's stream reads the map (the library rebuilds its derived copy at the next frame, which
-    # the pbr_ibl_device_ptr call above has requested)
-    if whole.is_cuda:
-        torch.cuda.current_stream(whole.device).synchronize()
+    ranges = [(16 * b, 16 * e) for b, e in zip(cuts[:-1], cuts[1:])]
+    overlapped = stream is not None and whole.is_cuda
+    if overlapped:
+        # ... its exchange on a second stream, behind an event ...
+        filtered = torch.cuda.Event()
+        filtered.record(stream)
+        comm = comm_stream if comm_stream is not None else _comm_stream(whole.device)
+        comm.wait_event(filtered)
+        with torch.cuda.stream(comm):
+            sent = all_gather_ranges(whole, ranges, rank, how=how)
+            exchanged = torch.cuda.Event()
+            exchanged.record(comm)
+    else:
+        renderer.synchronize()
+        sent = all_gather_ranges(whole, ranges, rank, how=how)
+        if whole.is_cuda:
+            torch.cuda.current_stream(whole.device).synchronize()
+    # ... and meanwhile the leading texels that nobody sends
+    if cuts[0]:
+        _lib.check(ctx, lib.pbr_ibl_prefilter_texels(ctx, size, mips, 1024, 0, cuts[0]))
+    if overlapped:
+        stream.wait_event(exchanged)     # the renderer's next work on the map follows the exchange
+    # the peers wrote through the library's pointer: ask for the map's derived copy to be rebuilt at the next frame
+    _lib.check(ctx, lib.pbr_ibl_device_ptr(ctx, _lib.MAP_PREFILTER, C.byref(ptr), C.byref(total)))
     return sent
+
+
+_comm_streams = {}
+
+
+def _comm_stream(device):
+    """One stream per device for the exchanges that overlap the renderer's work; created once."""
+    key = str(device)
+    if key not in _comm_streams:
+        _comm_streams[key] = torch.cuda.Stream(device)
+    return _comm_streams[key]
 
 
 _staging = {}
