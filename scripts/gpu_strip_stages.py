@@ -25,5 +25,5 @@ for name, (y0, y1) in (("whole frame", (0, H)), ("strip 3 of 8", sharding.strip_
             for f, _ in st._fields_:
                 if f.startswith("ms_"):
                     acc.setdefault(f, []).append(getattr(st, f))
-    print(name, {k: round(sum(v) / len(v) * 1000, 1) for k, v in acc.items()}, "us; set-up triangles", st.setup_triangles, flush=True)
+    print(name, {k: round(sum(v) / len(v) * 1000, 1) for k, v in acc.items()}, "us; set-up triangles", st.setup_triangles, "spilled references", st.binned_refs, "quads", st.uniform_quads, st.mixed_quads, flush=True)
 r.close()

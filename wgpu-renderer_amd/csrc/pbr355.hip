@@ -13,15 +13,19 @@
 // What a frame keeps between its three launches (append counters, tile bins, set-up triangles, shading records, the
 // two quad work lists) is laid out in it back to back.  Host code never uses the array by name: its address on each
 // device is taken once with hipGetSymbolAddress (pbr_create, with that device current) and travels as a pointer.
+// The two sets of a context's append counters are eight words apart (see PBR_LIST_SEGMENTS: so are their groups), and
+// the first sixteen words hold what the host looks at after every frame (the overflow flags).
+constexpr size_t kCounterBytes = PBR_COUNTER_WORDS * sizeof(uint32_t), kCounterHeadBytes = 16 * sizeof(uint32_t);
 #define PBR_STATIC_MAX_TILES 2048          // 32 x 32 pixel tiles of the row range, e.g. 1920 x 1080 (60 x 34 = 2040)
 #define PBR_STATIC_MAX_TRIANGLES 32768     // triangles x instances of the uploaded mesh
 namespace static_layout {
 constexpr size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 constexpr size_t kSetupCap = PBR_STATIC_MAX_TRIANGLES + PBR_STATIC_MAX_TRIANGLES / 4 + 4096;
 constexpr size_t kOverflowCap = kSetupCap * 2 + (1u << 16);
-constexpr size_t kQuads = (size_t)PBR_STATIC_MAX_TILES * (PBR_TILE / 2) * (PBR_TILE / 2);
-constexpr size_t kCounters = 0;                                                                   // 16 x u32
-constexpr size_t kTileCount = align_up(kCounters + 16 * sizeof(uint32_t));                        // [tiles] u32
+constexpr size_t kQuads = (size_t)(PBR_STATIC_MAX_TILES / PBR_LIST_SEGMENTS) * (PBR_TILE / 2) * (PBR_TILE / 2) * PBR_LIST_SEGMENTS;   // quad_list_len(PBR_STATIC_MAX_TILES)
+static_assert(PBR_STATIC_MAX_TILES % PBR_LIST_SEGMENTS == 0, "the quad lists' segments share the tiles evenly");
+constexpr size_t kCounters = 0;                                                                   // PBR_COUNTER_WORDS u32 (both sets)
+constexpr size_t kTileCount = align_up(kCounters + PBR_COUNTER_WORDS * sizeof(uint32_t));                        // [tiles] u32
 constexpr size_t kLiveInfo = align_up(kTileCount + PBR_STATIC_MAX_TILES * sizeof(uint32_t));      // [tiles] u64
 constexpr size_t kLiveTiles = align_up(kLiveInfo + PBR_STATIC_MAX_TILES * sizeof(uint64_t));      // [PBR_LIVE_TILE_CAP] u64
 constexpr size_t kZeroedBytes = align_up(kLiveTiles + PBR_LIVE_TILE_CAP * sizeof(uint64_t));      // cleared at the start of every call
@@ -322,7 +326,7 @@ int ensure_frame_buffers(PbrContext* c, int W, int rows, int n_tiles, int sample
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     free_dev(c->d_tile_count); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
     free_dev(c->d_live_info); free_dev(c->d_live_tiles);
-    const size_t n_quads = (size_t)n_tiles * (PBR_TILE / 2) * (PBR_TILE / 2);
+    const size_t n_quads = quad_list_len((size_t)n_tiles);
     HIP_TRY(c, hipMalloc(&c->quad_lists.uniform, sizeof(uint2) * n_quads));
     HIP_TRY(c, hipMalloc(&c->quad_lists.mixed_pos, sizeof(uint32_t) * n_quads));
     HIP_TRY(c, hipMalloc(&c->quad_lists.mixed_ids, sizeof(uint4) * n_quads));
@@ -663,7 +667,7 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   if (timed) {
     HIP_TRY(c, hipMemsetAsync(&counters[3], 0, sizeof(uint32_t), s));
     launch_count_covered(s, vis, (size_t)W * rows, samples, &counters[3]);
-    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->d_counters, kCounterBytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     (void)hipEventElapsedTime(&stats->ms_vertex, c->ev[0], c->ev[1]);
     (void)hipEventElapsedTime(&stats->ms_setup, c->ev[1], c->ev[2]);
@@ -671,11 +675,14 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
     (void)hipEventElapsedTime(&stats->ms_resolve, c->ev[3], c->ev[4]);
     (void)hipEventElapsedTime(&stats->ms_total, c->ev[0], c->ev[4]);
     const uint32_t* hc = c->h_counters + 8 * this_set;
-    stats->setup_triangles = hc[0];
-    stats->binned_refs = hc[1];   // references that spilled past a tile's own row
+    stats->setup_triangles = hc[0];   // pieces of clipped triangles; the whole ones are counted per segment
+    stats->binned_refs = hc[1];       // references that spilled past a tile's own row
     stats->covered_pixels = hc[3];
-    stats->uniform_quads = hc[6];
-    stats->mixed_quads = hc[7];
+    stats->uniform_quads = 0; stats->mixed_quads = 0;
+    for (int seg = 0; seg < PBR_LIST_SEGMENTS; ++seg) {
+      const uint32_t* group = hc + PBR_SEGMENT_FIRST + PBR_SEGMENT_WORDS * seg;
+      stats->uniform_quads += group[0]; stats->mixed_quads += group[1]; stats->setup_triangles += group[2];
+    }
     return check_sticky(c);
   }
   return PBR_OK;
@@ -718,10 +725,10 @@ int pbr_create(int device_ordinal, PbrContext** ctx_out) {
     pr->surface_blocks = dp.multiProcessorCount * surface_fast_blocks_per_cu();
   }
   for (auto& ev : c->ev) if ((e = hipEventCreate(&ev)) != hipSuccess) return bail("hipEventCreate", e);
-  if ((e = hipMalloc(&c->d_counters, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMalloc", e);
-  if ((e = hipMemset(c->d_counters, 0, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipMemset", e);
-  if ((e = hipHostMalloc(&c->h_counters, 16 * sizeof(uint32_t))) != hipSuccess) return bail("hipHostMalloc", e);
-  std::memset(c->h_counters, 0, 16 * sizeof(uint32_t));
+  if ((e = hipMalloc(&c->d_counters, kCounterBytes)) != hipSuccess) return bail("hipMalloc", e);
+  if ((e = hipMemset(c->d_counters, 0, kCounterBytes)) != hipSuccess) return bail("hipMemset", e);
+  if ((e = hipHostMalloc(&c->h_counters, kCounterBytes)) != hipSuccess) return bail("hipHostMalloc", e);
+  std::memset(c->h_counters, 0, kCounterBytes);
   if ((e = hipMalloc(&c->d_samples, sizeof(PrefilterSample) * PBR_PREFILTER_SAMPLES * PBR_MAX_LEVELS)) != hipSuccess) return bail("hipMalloc", e);
   if ((e = hipMalloc(&c->d_irr_tables, sizeof(float) * 2 * (512 + 128))) != hipSuccess) return bail("hipMalloc", e);
   {
@@ -802,14 +809,14 @@ int pbr_synchronize(PbrContext* c) {
   if (!c) return PBR_E_ARG;
   DeviceGuard guard(c->device);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, kCounterHeadBytes, hipMemcpyDeviceToHost));
   if (priv_of(c)->used_static && c->device < kMaxDevices && g_scratch_ptr[c->device]) {
     uint32_t flag = 0;   // the capacity flag of the last pbr_draw_frame_static on this device
     HIP_TRY(c, hipMemcpy(&flag, g_scratch_ptr[c->device] + static_layout::kCounters + 2 * sizeof(uint32_t), sizeof flag, hipMemcpyDeviceToHost));
     if (flag) return fail(c, PBR_E_STATE, flag == 1 ? "triangle setup buffer overflow" : "tile bin overflow list full");
   }
   for (PbrContext* slot : priv_of(c)->view_slots) {   // views 1, 2, ... of the multi-view passes count in their slots' counters
-    HIP_TRY(c, hipMemcpy(slot->h_counters, slot->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(slot->h_counters, slot->d_counters, kCounterHeadBytes, hipMemcpyDeviceToHost));
     if (check_sticky(slot)) return fail(c, PBR_E_STATE, "%s", slot->error.c_str());
   }
   return check_sticky(c);
@@ -1336,7 +1343,7 @@ int pbr_release_view_buffers(PbrContext* c) {
   PbrContextPrivate* pr = priv_of(c);
   int rc = PBR_OK;
   for (PbrContext* slot : pr->view_slots) {
-    HIP_TRY(c, hipMemcpy(slot->h_counters, slot->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(slot->h_counters, slot->d_counters, kCounterHeadBytes, hipMemcpyDeviceToHost));
     if (check_sticky(slot) && rc == PBR_OK) rc = fail(c, PBR_E_STATE, "%s", slot->error.c_str());   // an overflow of a queued pass is still reported
     slot->stream = slot->own_stream;
     (void)pbr_destroy(slot);
@@ -1369,7 +1376,7 @@ int pbr_draw_frame(PbrContext* c, const PbrFrameUniforms* u, int32_t w, int32_t 
     rc = draw_common(c, u, w, h, y0, y1, c->d_color, nullptr, vis_out != nullptr, stats);
     if (rc == PBR_OK) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
-      HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy(c->h_counters, c->d_counters, kCounterHeadBytes, hipMemcpyDeviceToHost));
       rc = check_sticky(c);
     }
     if (!(rc == PBR_E_STATE && c->enlarged_after_overflow)) break;

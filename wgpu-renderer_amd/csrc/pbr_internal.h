@@ -14,7 +14,7 @@
 #define PBR_MAX_SHARDS 4096         // most shards the prefilter's texels can be cut into
 #define PBR_LIVE_TILE_CAP 256   // most tiles that the rasteriser starts ahead of the rest (see LiveTiles)
 #define PBR_DENSE_TILE_REFS 48   // a tile with more triangle references than this is one of them
-#define PBR_BIN_CAP 256           // triangle references a tile keeps in its own row before spilling to the overflow list
+#define PBR_BIN_CAP 1024          // triangle references a tile keeps in its own row before spilling to the overflow list
 
 // An rgba8 texture with its mip chain in one allocation.  Every level is stored in blocks of 8 x 4
 // texels (128 bytes, one cache line), blocks row by row: a bilinear footprint, and the footprints of
@@ -100,6 +100,27 @@ struct QuadLists {
   uint4* mixed_ids;     // ... and the ids of their pixels (0,0), (1,0), (0,1), (1,1); 0 = background
 };
 
+// The append counters of a frame.  One counter in device memory takes about a hundred atomics per microsecond, however
+// many wavefronts issue them: an 8K frame of a hundred meshes has ten thousand tiles with geometry and twenty-four
+// thousand wavefronts of triangles, and with one atomic each on one address its launches lasted as long as those
+// atomics queued (set-up 383 us with, 125 us without).  So whatever is counted once per tile or per wavefront is
+// counted in one of PBR_LIST_SEGMENTS groups of counters, 256 bytes apart; the quad lists are cut into as many
+// segments, tile t appends to segment t % PBR_LIST_SEGMENTS, and a segment has room for all the quads of the tiles
+// that can fall to it.  A set of counters: [0] pieces of clipped triangles set up, [1] bin references spilled,
+// [2] overflow flag, [3] covered pixels (statistics), [4] listed tiles, then from word PBR_SEGMENT_FIRST every
+// PBR_SEGMENT_WORDS words a group: [0] uniform quads, [1] mixed quads (one 64-bit atomic reserves room in both),
+// [2] whole triangles set up (statistics).  Alternate frames of a context use two sets: the second lies eight words
+// behind the first, group by group, so both fit PBR_COUNTER_WORDS words.
+#define PBR_LIST_SEGMENTS 32
+#define PBR_SEGMENT_WORDS 64
+#define PBR_SEGMENT_FIRST 64
+#define PBR_COUNTER_WORDS (PBR_SEGMENT_FIRST + PBR_LIST_SEGMENTS * PBR_SEGMENT_WORDS)
+// quads a segment of the lists holds in a frame of n_tiles tiles, and the lists' length for it
+static inline __host__ __device__ uint32_t quad_segment_cap(uint32_t n_tiles) {
+  return ((n_tiles + PBR_LIST_SEGMENTS - 1u) / PBR_LIST_SEGMENTS) * (uint32_t)((PBR_TILE / 2) * (PBR_TILE / 2));
+}
+static inline __host__ __device__ size_t quad_list_len(size_t n_tiles) { return (size_t)quad_segment_cap((uint32_t)n_tiles) * PBR_LIST_SEGMENTS; }
+
 struct FrameParams {
   PbrFrameUniforms u;
   float pv[16];             // projection * view
@@ -155,12 +176,12 @@ struct PbrContext {
   TriRecord* d_records = nullptr; size_t record_cap = 0;   // one per triangle of every instance
   uint32_t* d_tile_count = nullptr; uint32_t* d_bins = nullptr; size_t tile_cap = 0; uint32_t* d_tile_live = nullptr;   // [tiles], [tiles][PBR_BIN_CAP]
   unsigned long long* d_live_info = nullptr; unsigned long long* d_live_tiles = nullptr; unsigned long long live_serial = 0;   // see LiveTiles
-  QuadLists quad_lists = {nullptr, nullptr, nullptr};                                  // work lists of the resolve, each [tiles * 256]
+  QuadLists quad_lists = {nullptr, nullptr, nullptr};                                  // work lists of the resolve, each [quad_list_len(tiles)]
   uint2* d_overflow = nullptr; size_t overflow_cap = 0;                                // (tile, setup index) pairs
   size_t min_setup_cap = 0, min_overflow_cap = 0;         // raised when a frame overflowed one of the two
   size_t forced_setup_cap = 0, forced_overflow_cap = 0;   // pbr_debug_set_capacity: exact capacities, until an overflow enlarges them
   bool enlarged_after_overflow = false;
-  uint32_t* d_counters = nullptr; // two sets of 8, used by alternate frames: [0] setup count, [1] bin refs, [2] overflow flag, [3] covered pixels, [6], [7] uniform and mixed quads
+  uint32_t* d_counters = nullptr; // PBR_COUNTER_WORDS words: two sets, used by alternate frames (see PBR_LIST_SEGMENTS)
   bool capture_depth = false;
   uint32_t* h_counters = nullptr; // pinned mirror
   uint32_t* d_vis = nullptr;      float* d_depth = nullptr; uint8_t* d_color = nullptr; size_t pix_cap = 0, vis_cap = 0;   // vis / depth hold vis_cap entries (one per sample)

@@ -115,6 +115,16 @@ __device__ unsigned long long g_setup_trace[16384][8];
 #define SETUP_TRACE(slot) do { } while (0)
 #endif
 
+// Zeroes the append counters of the set the next frame counts in (by the first threads of one workgroup of the raster
+// launch; the overflow flag [2] stays until the host has seen it, the covered pixels [3] are cleared where they are counted).
+PBR_DEV void rearm_counters(uint32_t* __restrict__ next_counters, int tid) {
+  if (tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[4] = 0u; }
+  if (tid < PBR_LIST_SEGMENTS) {
+    uint32_t* group = next_counters + PBR_SEGMENT_FIRST + PBR_SEGMENT_WORDS * tid;
+    group[0] = 0u; group[1] = 0u; group[2] = 0u;
+  }
+}
+
 PBR_DEV void bin_store(const BinTargets& bt, uint32_t tile, uint32_t pos, uint32_t slot) {
   if (pos == PBR_DENSE_TILE_REFS) {   // the tile has just become one of the full ones: list it (see LiveTiles)
     const uint32_t k = atomicAdd(&bt.counters[4], 1u);
@@ -163,7 +173,7 @@ PBR_DEV void emit_piece(uint32_t id, float4 a, float4 b, float4 c, const FramePa
   SetupTri t;
   TileBox box;
   if (!make_setup(id, a, b, c, p, t, box)) return;
-  const uint32_t slot = atomicAdd(&bt.counters[0], 1u);
+  const uint32_t slot = (uint32_t)p->n_tris * (uint32_t)p->n_instances + atomicAdd(&bt.counters[0], 1u);   // behind the whole triangles' entries (bin_wave)
   if (slot >= bt.setup_cap) { bt.counters[2] = 1u; return; }
   bt.setup[slot] = t;
   const int bw = box.tx1 - box.tx0 + 1, n_tiles = bw * (box.ty1 - box.ty0 + 1);
@@ -184,30 +194,24 @@ PBR_DEV void wave_sync() {   // orders this wavefront's LDS traffic for the comp
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// Appends the wavefront's pending triangles to the setup list and references them from the tiles of their bounding
-// boxes.  An atomic on device memory that returns its value takes some 2 us here, and one per reference, from 64 lanes
-// whose triangles are neighbours and so count on the same few tiles, took 6 us a round (measured per workgroup with
-// the launch's timeline): the set-up launch spent more than half its time in them.  So the wavefront first counts
-// its references per tile in LDS (the tiles of its triangles nearly always fit a 16 x 16 window), then one lane per
-// tile adds the tile's count to the tile's counter in memory - a single round of atomics, every one on a different
-// address and in flight together with the one that reserves the setup slots - and the lanes take their positions from
-// LDS again.  The order of the references inside a tile's row differs from run to run, as it did before; the
-// rasteriser's result does not depend on it (nearest fragment, lowest triangle number on ties).
+// Enters the wavefront's pending triangles in the setup list and references them from the tiles of their bounding
+// boxes.  A whole triangle's entry in the list is its own number: the list has a place for every triangle of every
+// instance (and room behind them for the pieces of clipped ones), so nothing is reserved and no wavefront waits for an
+// atomic on a counter all the others use too (see PBR_LIST_SEGMENTS; the count of the statistics goes to one of the
+// segments' counters, and nobody waits for it).  An atomic on device memory that returns its value takes some 2 us
+// here, and one per reference, from 64 lanes whose triangles are neighbours and so count on the same few tiles, took
+// 6 us a round (measured per workgroup with the launch's timeline): the set-up launch spent more than half its time in
+// them.  So the wavefront first counts its references per tile in LDS (the tiles of its triangles nearly always fit a
+// 16 x 16 window), then one lane per tile adds the tile's count to the tile's counter in memory - a single round of
+// atomics, every one on a different address - and the lanes take their positions from LDS again.  The order of the
+// references inside a tile's row differs from run to run; the rasteriser's result does not depend on it (nearest
+// fragment, lowest triangle number on ties).
 PBR_DEV void bin_wave(const FrameParams* p, const BinTargets& bt, const Pending& pd, int lane, BinWindow* w) {
   const bool have = pd.n_tiles > 0;
   const unsigned long long have_mask = __ballot(have);
   if (!have_mask) return;
-  const int leader = __ffsll((long long)have_mask) - 1;
-  // The setup slots of the wavefront's triangles: one atomic by one lane, waited for only where the slots are used, so
-  // that its round trip overlaps that of the tiles' atomics below.  The offset is hidden from the compiler: with an
-  // address it can prove uniform it would turn this into its own one-lane atomic followed at once by a wait and a
-  // broadcast.
-  uint32_t slot_base = 0u;
-  if (lane == leader) {
-    uint32_t zero = 0u;
-    asm volatile("" : "+v"(zero));
-    slot_base = atomicAdd(bt.counters + zero, (uint32_t)__popcll(have_mask));
-  }
+  if (lane == __ffsll((long long)have_mask) - 1)
+    atomicAdd(bt.counters + PBR_SEGMENT_FIRST + PBR_SEGMENT_WORDS * (blockIdx.x % PBR_LIST_SEGMENTS) + 2, (uint32_t)__popcll(have_mask));
   const bool small = have && pd.n_tiles <= 16;
   bool window = false;
   int minx = 0, miny = 0;
@@ -246,7 +250,7 @@ PBR_DEV void bin_wave(const FrameParams* p, const BinTargets& bt, const Pending&
     wave_sync();
   }
   SETUP_TRACE(5);
-  const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)slot_base, leader) + (uint32_t)__popcll(have_mask & ((1ull << lane) - 1ull));
+  const uint32_t slot = pd.t.id;
   const bool fits = slot < bt.setup_cap;
   if (have && !fits) bt.counters[2] = 1u;   // the frame is drawn again with a larger list
   if (have && fits) bt.setup[slot] = pd.t;
@@ -380,10 +384,16 @@ PBR_DEV bool setup_one(const FrameParams* p, const VertexOut* vout, const uint32
     for (int k = 0; k < 3; ++k) { l += v[k].x < -v[k].w; r += v[k].x > v[k].w; bt_ += v[k].y < -v[k].w; tp += v[k].y > v[k].w; }
     if (l == 3 || r == 3 || bt_ == 3 || tp == 3) return false;   // beside the viewport: no pixel centre can be covered
   }
-  write_record(bt.records + id, va, vb, vc, p->W, p->H);
+  // The shading record is only ever read through a pixel that shows the triangle: a triangle that is culled (turned
+  // away, without area, or between pixel centres) needs none, and in a scene of small triangles that is every other
+  // one (144 bytes each).  A triangle that crosses a clip plane gets its record before it is known which of its pieces
+  // survive.
+  if (!inside_all) { write_record(bt.records + id, va, vb, vc, p->W, p->H); SETUP_TRACE(2); return true; }
+  if (make_setup(id, a, b, c, p, pending.t, pending.box)) {
+    pending.n_tiles = (pending.box.tx1 - pending.box.tx0 + 1) * (pending.box.ty1 - pending.box.ty0 + 1);
+    write_record(bt.records + id, va, vb, vc, p->W, p->H);
+  }
   SETUP_TRACE(2);
-  if (!inside_all) return true;
-  if (make_setup(id, a, b, c, p, pending.t, pending.box)) pending.n_tiles = (pending.box.tx1 - pending.box.tx0 + 1) * (pending.box.ty1 - pending.box.ty0 + 1);
   return false;
 }
 
@@ -486,6 +496,9 @@ __device__ unsigned long long g_raster_trace[32768][8];
 #endif
 
 constexpr int kRasterThreads = 256, kRasterWaves = kRasterThreads / 64;
+// Small triangles (bounding box within the tile at most 16 x 16 pixels, 32-bit edge functions) are swept four at a time,
+// each by sixteen lanes as 4 x 4 pixel blocks; a wavefront stages this many of them in LDS per round.
+constexpr int kSmallBatch = 32, kSmallBoxPixels = 16;
 
 // grid_row: the workgroup's row in its view's grid of (tiles_x, listed_rows + tiles_y) workgroups.
 __device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, const int grid_row, const SetupTri* __restrict__ setup,
@@ -496,10 +509,12 @@ __device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, c
                                             const LiveTiles& live, int listed_rows, int listed_parts) {
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE];
   __shared__ uint32_t s_pairs[kRasterWaves], s_base[2];
+  // staging of the small triangles a wavefront has set up, for the four-at-a-time sweep below: 16 dwords per triangle
+  __shared__ uint4 s_tri[kRasterWaves][kSmallBatch][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // The frame's append counters come in two sets used by alternate frames; this launch re-arms the set of
   // the next frame, which nothing is using (the previous frame, its last user, finished before this launch began).
-  if (blockIdx.x == 0 && grid_row == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[4] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
+  if (blockIdx.x == 0 && grid_row == 0) rearm_counters(next_counters, tid);
   // The first rows of workgroups take the tiles the set-up launch listed as the fullest: the frame waits for
   // those, so they must not queue behind thousands of skybox tiles (the fullest tile of the 4K benchmark frame used to
   // start 7 us into the launch and end it at 38 us).  Every tile also has a workgroup of its own after those, which
@@ -619,7 +634,74 @@ __device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, c
         }
         if (narrow) tl |= 8;
       }
-      unsigned long long todo = __ballot(keep);
+      // Small triangles first, four at a time.  Serving a triangle to all 64 lanes costs the same ~60 instructions of
+      // lane reads and scalar set-up whether it covers three pixels or three hundred, at the rate of a wavefront that
+      // is alone on its SIMD, and an 8 x 8 block per step is mostly empty lanes for a triangle a few pixels wide.  Here
+      // every lane that holds a small triangle writes its sixteen parameters to LDS once; then each group of sixteen
+      // lanes takes every fourth staged triangle, reads its parameters back as a broadcast into vector registers and
+      // walks its bounding box in 4 x 4 blocks, independently of the other three groups.  Same integers, same f32
+      // operations per pixel as the one-triangle sweep below: the keys offered to ds_min_u64 are the same.
+#ifdef PBR_NO_SMALL_SWEEP
+      const bool small = false;
+#else
+      const bool small = keep && (tl & 8) && (((box >> 8) & 255) - (box & 255)) < kSmallBoxPixels && ((box >> 24) - ((box >> 16) & 255)) < kSmallBoxPixels;
+#endif
+      const unsigned long long small_mask = __ballot(small);
+      if (small_mask) {
+        const int n_small = __popcll(small_mask), rank = __popcll(small_mask & ((1ull << lane) - 1ull));
+        const int group = lane >> 4, gl = lane & 15, gx = gl & 3, gy = gl >> 2;
+        for (int base = 0; base < n_small; base += kSmallBatch) {
+          if (small && rank >= base && rank < base + kSmallBatch) {
+            uint4* rec = s_tri[wave][rank - base];
+            const int c1 = (tl & 2) ? 0 : -1, c2 = (tl & 4) ? 0 : -1;
+            rec[0] = make_uint4((uint32_t)((int)e0 + ((tl & 1) ? 0 : -1)), (uint32_t)(int)e1, (uint32_t)(int)e2, (uint32_t)a0);
+            rec[1] = make_uint4((uint32_t)a1, (uint32_t)a2, (uint32_t)b0, (uint32_t)b1);
+            rec[2] = make_uint4((uint32_t)b2, __float_as_uint(z0), __float_as_uint(dz1), __float_as_uint(dz2));
+            rec[3] = make_uint4(__float_as_uint(inv_area), id + 1u, (uint32_t)box, (uint32_t)(c1 & 1) | ((uint32_t)(c2 & 1) << 1));
+          }
+          wave_sync();
+          const int count = min(kSmallBatch, n_small - base);
+          int slot = group;
+          bool have = false;
+          int E0n = 0, E1n = 0, E2n = 0, A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0, C1 = 0, C2 = 0, bx0 = 0, bx1 = 0, by1 = 0, bx = 0, by = 0;
+          float Z0 = 0, DZ1 = 0, DZ2 = 0, IA = 0;
+          uint32_t ID = 0;
+          for (;;) {
+            if (!have && slot < count) {
+              const uint4* rec = s_tri[wave][slot];
+              const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+              E0n = (int)r0.x; E1n = (int)r0.y; E2n = (int)r0.z; A0 = (int)r0.w;
+              A1 = (int)r1.x; A2 = (int)r1.y; B0 = (int)r1.z; B1 = (int)r1.w;
+              B2 = (int)r2.x; Z0 = __uint_as_float(r2.y); DZ1 = __uint_as_float(r2.z); DZ2 = __uint_as_float(r2.w);
+              IA = __uint_as_float(r3.x); ID = r3.y;
+              bx0 = (int)(r3.z & 255u); bx1 = (int)((r3.z >> 8) & 255u); by = (int)((r3.z >> 16) & 255u); by1 = (int)(r3.z >> 24);
+              C1 = -(int)(r3.w & 1u); C2 = -(int)((r3.w >> 1) & 1u);
+              bx = bx0;
+              slot += 4;
+              have = true;
+            }
+            if (!__ballot(have)) break;
+            if (have) {
+              const int x = bx + gx, y = by + gy;
+              if (x <= bx1 && y <= by1) {
+                const int xs = x * 256, ys = y * 256;
+                const int f0 = E0n + __mul24(A0, xs) + __mul24(B0, ys);
+                const int f1 = E1n + __mul24(A1, xs) + __mul24(B1, ys);
+                const int f2 = E2n + __mul24(A2, xs) + __mul24(B2, ys);
+                if ((f0 | (f1 + C1) | (f2 + C2)) >= 0) {
+                  const float l1 = mul_rn((float)f1, IA), l2 = mul_rn((float)f2, IA);
+                  const float z = add_rn(add_rn(Z0, mul_rn(l1, DZ1)), mul_rn(l2, DZ2));
+                  atomicMin(&s_key[y * PBR_TILE + x], ((unsigned long long)depth_key(z) << 32) | ID);
+                }
+              }
+              bx += 4;
+              if (bx > bx1) { bx = bx0; by += 4; have = by <= by1; }
+            }
+          }
+          wave_sync();   // the next round overwrites the staging
+        }
+      }
+      unsigned long long todo = __ballot(keep && !small);
       const int lx = lane & 7, ly = lane >> 3;
 #ifdef PBR_SURFACE_TRACE
       if (chunk == 0) { RASTER_TRACE(4, wall_clock64()); RASTER_TRACE(5, (unsigned long long)__popcll(todo)); }
@@ -750,12 +832,15 @@ __device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, c
   if (tid == 0) {
     const uint32_t tu = (s_pairs[0] & 0xffffu) + (s_pairs[1] & 0xffffu) + (s_pairs[2] & 0xffffu) + (s_pairs[3] & 0xffffu);
     const uint32_t tm = (s_pairs[0] >> 16) + (s_pairs[1] >> 16) + (s_pairs[2] >> 16) + (s_pairs[3] >> 16);
-    // the two lists' counters are neighbours on an 8-byte boundary: one 64-bit atomic reserves room in both (two
-    // 32-bit ones are issued one after the other's answer, 2 us each at the end of every tile with geometry, the
-    // frame's fullest tile included)
+    // the tile appends to its segment of the lists (see PBR_LIST_SEGMENTS).  The segment's two counters are neighbours
+    // on an 8-byte boundary: one 64-bit atomic reserves room in both (two 32-bit ones are issued one after the
+    // other's answer, 2 us each at the end of every tile with geometry, the frame's fullest tile included)
+    const uint32_t segment = (uint32_t)tile % PBR_LIST_SEGMENTS;
     unsigned long long at = 0ull;
-    if (tu | tm) at = atomicAdd(reinterpret_cast<unsigned long long*>(counters + 6), (unsigned long long)tu | ((unsigned long long)tm << 32));
-    s_base[0] = (uint32_t)at; s_base[1] = (uint32_t)(at >> 32);
+    if (tu | tm)
+      at = atomicAdd(reinterpret_cast<unsigned long long*>(counters + PBR_SEGMENT_FIRST + PBR_SEGMENT_WORDS * segment), (unsigned long long)tu | ((unsigned long long)tm << 32));
+    const uint32_t first = segment * quad_segment_cap((uint32_t)(p->tiles_x * p->tiles_y));
+    s_base[0] = first + (uint32_t)at; s_base[1] = first + (uint32_t)(at >> 32);
   }
   __syncthreads();
   uint32_t at_u = s_base[0], at_m = s_base[1];
@@ -823,7 +908,7 @@ __global__ void __launch_bounds__(256) raster_msaa_kernel(const FrameParams fram
   __shared__ unsigned long long s_key[PBR_TILE * PBR_TILE * 4];
   const int tile = blockIdx.y * p->tiles_x + blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) { next_counters[0] = 0u; next_counters[1] = 0u; next_counters[4] = 0u; next_counters[6] = 0u; next_counters[7] = 0u; }
+  if (blockIdx.x == 0 && blockIdx.y == 0) rearm_counters(next_counters, tid);
   const int px0 = blockIdx.x * PBR_TILE, py0 = p->y0 + blockIdx.y * PBR_TILE;
   const uint32_t n = tile_count[tile];
   const uint32_t n_row = min(n, (uint32_t)PBR_BIN_CAP);

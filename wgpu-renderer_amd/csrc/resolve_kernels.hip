@@ -837,6 +837,42 @@ constexpr int kXcds = 8;
 constexpr int kTraceSlots = 16;
 __device__ unsigned long long g_surface_trace[1024 * 16][kTraceSlots];
 #endif
+// The quad lists of one view as the surface kernels walk them.  The rasteriser appends to PBR_LIST_SEGMENTS segments
+// of each list; here the segments' quads are cut into items of 16 quads (one wavefront's worth) and the items of all
+// segments numbered in one run, segment after segment: per segment (the number of its first item, its quads).
+struct SegmentTable { uint2 uniform[PBR_LIST_SEGMENTS], mixed[PBR_LIST_SEGMENTS]; };
+static_assert(PBR_LIST_SEGMENTS == 32, "one half wavefront scans a view's segments");
+// x + (x of the lane `shift` places down in the same row of 16 lanes, or 0)
+template <int SHIFT>
+PBR_DEV uint32_t add_row_shr(uint32_t x) { return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x110 + SHIFT, 0xf, 0xf, true); }
+// Built by 32 consecutive lanes (seg = lane & 31, the wavefront's other half may build another view's) from the
+// frame's counters; the lists' totals in items come back in every lane.
+PBR_DEV void build_segment_table(SegmentTable* t, const uint32_t* __restrict__ counters, int lane, uint32_t& items_u, uint32_t& items_m) {
+  const int seg = lane & 31;
+  const uint2 n = *reinterpret_cast<const uint2*>(counters + PBR_SEGMENT_FIRST + PBR_SEGMENT_WORDS * seg);
+  const uint32_t own_u = (n.x + 15u) >> 4, own_m = (n.y + 15u) >> 4;
+  // running sums over the 32 lanes: within the rows of 16 by four shifted additions, then the upper row takes the lower row's total
+  uint32_t run_u = add_row_shr<8>(add_row_shr<4>(add_row_shr<2>(add_row_shr<1>(own_u))));
+  uint32_t run_m = add_row_shr<8>(add_row_shr<4>(add_row_shr<2>(add_row_shr<1>(own_m))));
+  const bool upper = (lane & 32) != 0;   // (values of lanes that are switched off are read below, and not used)
+  auto from_lane = [&](uint32_t x, int l) { return (uint32_t)(upper ? __builtin_amdgcn_readlane((int)x, 32 + l) : __builtin_amdgcn_readlane((int)x, l)); };
+  const uint32_t low_u = from_lane(run_u, 15), low_m = from_lane(run_m, 15);
+  if (seg >= 16) { run_u += low_u; run_m += low_m; }
+  t->uniform[seg] = make_uint2(run_u - own_u, n.x); t->mixed[seg] = make_uint2(run_m - own_m, n.y);
+  items_u = from_lane(run_u, 31); items_m = from_lane(run_m, 31);
+}
+// Where item `item` (the same in every lane) of a list lies: the position in the list of the quad this lane's group of
+// four works on, and whether there is one (the last item of a segment may be short).  One LDS read: the lanes hold the
+// table's entries, and the segment's own is read from its lane.
+PBR_DEV uint32_t locate_quad(const uint2* table, uint32_t item, uint32_t segment_cap, int lane, bool& live) {
+  const uint2 e = table[lane & 31];
+  const int seg = __popc((uint32_t)__ballot(e.x <= item)) - 1;   // the last segment that starts at or before the item
+  const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)e.x, seg), n = (uint32_t)__builtin_amdgcn_readlane((int)e.y, seg);
+  const uint32_t q = (item - first) * 16u + (uint32_t)(lane >> 2);
+  live = q < n;
+  return live ? (uint32_t)seg * segment_cap + q : 0u;
+}
+
 // What the views of one pass differ in, as kernel arguments (a single frame is a pass of one view).
 struct SurfaceViews {
   FrameParams fp[PBR_MAX_VIEWS];
@@ -858,33 +894,36 @@ __global__ void __launch_bounds__(THREADS) resolve_surface_fast_kernel(const Sur
   __shared__ float s_srgb[256];
   __shared__ uint32_t s_next;
   // per view: items of this workgroup in all, its mixed ones, first mixed item, first uniform item, quads in the two lists
-  __shared__ uint32_t s_own[PBR_MAX_VIEWS], s_own_mixed[PBR_MAX_VIEWS], s_m_begin[PBR_MAX_VIEWS], s_u_begin[PBR_MAX_VIEWS], s_n_uniform[PBR_MAX_VIEWS],
-      s_n_mixed[PBR_MAX_VIEWS];
+  __shared__ uint32_t s_own[PBR_MAX_VIEWS], s_own_mixed[PBR_MAX_VIEWS], s_m_begin[PBR_MAX_VIEWS], s_u_begin[PBR_MAX_VIEWS];
+  __shared__ SegmentTable s_segments[PBR_MAX_VIEWS];
+  static_assert(THREADS >= 32 * PBR_MAX_VIEWS, "32 threads per view build its segment table");
   for (int i = threadIdx.x; i < 256; i += THREADS) s_srgb[i] = srgb_lut[i];
   if (threadIdx.x == 0) s_next = 0u;
-  if ((int)threadIdx.x < PBR_MAX_VIEWS) {
-    const int view = threadIdx.x;
-    uint32_t n_uniform = 0u, n_mixed = 0u;
-    if (view < n_views) { const uint32_t* counters = sv.counters[view]; n_uniform = counters[6]; n_mixed = counters[7]; }
-    const uint32_t items_mixed = (n_mixed + 15u) >> 4, items_uniform = (n_uniform + 15u) >> 4;
-    // gridDim.x is a multiple of kXcds; v runs over the workgroups XCD by XCD
-    const uint32_t per_xcd = gridDim.x / kXcds, v = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds, nv = gridDim.x;
-    const uint32_t m_begin = (uint32_t)((unsigned long long)items_mixed * v / nv), m_end = (uint32_t)((unsigned long long)items_mixed * (v + 1) / nv);
-    const uint32_t u_begin = (uint32_t)((unsigned long long)items_uniform * v / nv), u_end = (uint32_t)((unsigned long long)items_uniform * (v + 1) / nv);
-    s_own_mixed[view] = m_end - m_begin; s_own[view] = (m_end - m_begin) + (u_end - u_begin);
-    s_m_begin[view] = m_begin; s_u_begin[view] = u_begin; s_n_uniform[view] = n_uniform; s_n_mixed[view] = n_mixed;
+  if ((int)threadIdx.x < 32 * n_views) {
+    const int view = threadIdx.x >> 5;
+    uint32_t items_uniform, items_mixed;
+    build_segment_table(&s_segments[view], sv.counters[view], threadIdx.x & 63, items_uniform, items_mixed);
+    if ((threadIdx.x & 31) == 0) {
+      // gridDim.x is a multiple of kXcds; v runs over the workgroups XCD by XCD
+      const uint32_t per_xcd = gridDim.x / kXcds, v = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds, nv = gridDim.x;
+      const uint32_t m_begin = (uint32_t)((unsigned long long)items_mixed * v / nv), m_end = (uint32_t)((unsigned long long)items_mixed * (v + 1) / nv);
+      const uint32_t u_begin = (uint32_t)((unsigned long long)items_uniform * v / nv), u_end = (uint32_t)((unsigned long long)items_uniform * (v + 1) / nv);
+      s_own_mixed[view] = m_end - m_begin; s_own[view] = (m_end - m_begin) + (u_end - u_begin);
+      s_m_begin[view] = m_begin; s_u_begin[view] = u_begin;
+    }
+  } else if ((int)threadIdx.x < 32 * PBR_MAX_VIEWS && (threadIdx.x & 31) == 0) {
+    s_own[threadIdx.x >> 5] = 0u;
   }
   __syncthreads();
   // every wave keeps the views' figures in scalar registers (read once from LDS) and picks its item's by comparisons
   auto uniform_u32 = [](const uint32_t* lds) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)*lds); };
-  struct PerView { uint32_t own, own_mixed, m_begin, u_begin, n_uniform, n_mixed; };
+  struct PerView { uint32_t own, own_mixed, m_begin, u_begin; };
   PerView pv[PBR_MAX_VIEWS];
 #pragma unroll
   for (int v = 0; v < PBR_MAX_VIEWS; ++v) {
-    pv[v] = PerView{0u, 0u, 0u, 0u, 0u, 0u};
-    if (v < n_views)   // (a single frame reads one view's six figures, not four views')
-      pv[v] = PerView{uniform_u32(&s_own[v]), uniform_u32(&s_own_mixed[v]), uniform_u32(&s_m_begin[v]), uniform_u32(&s_u_begin[v]), uniform_u32(&s_n_uniform[v]),
-                      uniform_u32(&s_n_mixed[v])};
+    pv[v] = PerView{0u, 0u, 0u, 0u};
+    if (v < n_views)   // (a single frame reads one view's four figures, not four views')
+      pv[v] = PerView{uniform_u32(&s_own[v]), uniform_u32(&s_own_mixed[v]), uniform_u32(&s_m_begin[v]), uniform_u32(&s_u_begin[v])};
   }
   const uint32_t own0 = pv[0].own, own1 = pv[1].own, own2 = pv[2].own, own3 = pv[3].own;
   const uint32_t own_all = own0 + own1 + own2 + own3;
@@ -907,16 +946,17 @@ __global__ void __launch_bounds__(THREADS) resolve_surface_fast_kernel(const Sur
     uint32_t* __restrict__ rgba8 = sv.rgba8[view];
     const uint32_t own_mixed = pick(pv[0].own_mixed, pv[1].own_mixed, pv[2].own_mixed, pv[3].own_mixed);
     const bool uniform_item = k >= own_mixed;
+    const SegmentTable& segments = s_segments[view];
+    const uint32_t segment_cap = quad_segment_cap((uint32_t)(p->tiles_x * p->tiles_y));
+    bool live;
     if (uniform_item) {
-      const uint32_t q = (pick(pv[0].u_begin, pv[1].u_begin, pv[2].u_begin, pv[3].u_begin) + k - own_mixed) * 16u + (uint32_t)(lane >> 2);
-      const bool live = q < pick(pv[0].n_uniform, pv[1].n_uniform, pv[2].n_uniform, pv[3].n_uniform);
-      const uint2 e = sv.lists[view].uniform[live ? q : 0u];
+      const uint32_t q = locate_quad(segments.uniform, pick(pv[0].u_begin, pv[1].u_begin, pv[2].u_begin, pv[3].u_begin) + k - own_mixed, segment_cap, lane, live);
+      const uint2 e = sv.lists[view].uniform[q];
       surface_fast_quad<true>(p, in, records, s_srgb, rgba8, (int)(e.x & 0xffffu) * 2, p->y0 + (int)(e.x >> 16) * 2, e.y, live);
     } else {
-      const uint32_t q = (pick(pv[0].m_begin, pv[1].m_begin, pv[2].m_begin, pv[3].m_begin) + k) * 16u + (uint32_t)(lane >> 2);
-      const bool live = q < pick(pv[0].n_mixed, pv[1].n_mixed, pv[2].n_mixed, pv[3].n_mixed);
-      const uint32_t pos = sv.lists[view].mixed_pos[live ? q : 0u];
-      const uint32_t id = reinterpret_cast<const uint32_t*>(sv.lists[view].mixed_ids)[(live ? q : 0u) * 4u + (uint32_t)(lane & 3)];
+      const uint32_t q = locate_quad(segments.mixed, pick(pv[0].m_begin, pv[1].m_begin, pv[2].m_begin, pv[3].m_begin) + k, segment_cap, lane, live);
+      const uint32_t pos = sv.lists[view].mixed_pos[q];
+      const uint32_t id = reinterpret_cast<const uint32_t*>(sv.lists[view].mixed_ids)[q * 4u + (uint32_t)(lane & 3)];
       surface_fast_quad<false>(p, in, records, s_srgb, rgba8, (int)(pos & 0xffffu) * 2, p->y0 + (int)(pos >> 16) * 2, id, live);
     }
 #ifdef PBR_SURFACE_TRACE
@@ -939,11 +979,18 @@ __global__ void __launch_bounds__(kGeneralThreads) resolve_surface_lists_kernel(
   const FrameParams* __restrict__ p = &frame_params;
   __shared__ float s_srgb[256];
   __shared__ uint32_t s_next;
+  __shared__ SegmentTable s_segments;
+  __shared__ uint32_t s_items[2];
   if (threadIdx.x < 256) s_srgb[threadIdx.x] = srgb_lut[threadIdx.x];
   if (threadIdx.x == 0) s_next = 0u;
+  if (threadIdx.x < 32) {
+    uint32_t iu, im;
+    build_segment_table(&s_segments, counters, threadIdx.x, iu, im);
+    if (threadIdx.x == 0) { s_items[0] = iu; s_items[1] = im; }
+  }
   __syncthreads();
-  const uint32_t n_uniform = counters[6], n_mixed = counters[7];
-  const uint32_t items_mixed = (n_mixed + 15u) >> 4, items_uniform = (n_uniform + 15u) >> 4;
+  const uint32_t items_uniform = s_items[0], items_mixed = s_items[1];
+  const uint32_t segment_cap = quad_segment_cap((uint32_t)(p->tiles_x * p->tiles_y));
   const uint32_t per_xcd = gridDim.x / kXcds, v = (blockIdx.x % kXcds) * per_xcd + blockIdx.x / kXcds, nv = gridDim.x;
   const uint32_t m_begin = (uint32_t)((unsigned long long)items_mixed * v / nv), m_end = (uint32_t)((unsigned long long)items_mixed * (v + 1) / nv);
   const uint32_t u_begin = (uint32_t)((unsigned long long)items_uniform * v / nv), u_end = (uint32_t)((unsigned long long)items_uniform * (v + 1) / nv);
@@ -957,15 +1004,12 @@ __global__ void __launch_bounds__(kGeneralThreads) resolve_surface_lists_kernel(
     uint32_t pos, id;
     bool live;
     if (k >= own_mixed) {
-      const uint32_t q = (u_begin + k - own_mixed) * 16u + (uint32_t)(lane >> 2);
-      live = q < n_uniform;
-      const uint2 e = lists.uniform[live ? q : 0u];
+      const uint2 e = lists.uniform[locate_quad(s_segments.uniform, u_begin + k - own_mixed, segment_cap, lane, live)];
       pos = e.x; id = e.y;
     } else {
-      const uint32_t q = (m_begin + k) * 16u + (uint32_t)(lane >> 2);
-      live = q < n_mixed;
-      pos = lists.mixed_pos[live ? q : 0u];
-      id = reinterpret_cast<const uint32_t*>(lists.mixed_ids)[(live ? q : 0u) * 4u + (uint32_t)sub];
+      const uint32_t q = locate_quad(s_segments.mixed, m_begin + k, segment_cap, lane, live);
+      pos = lists.mixed_pos[q];
+      id = reinterpret_cast<const uint32_t*>(lists.mixed_ids)[q * 4u + (uint32_t)sub];
     }
     if (!live) id = 0u;
     const int qx = (int)(pos & 0xffffu) * 2, qy = p->y0 + (int)(pos >> 16) * 2;
