@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter passes over a few 4K frames (one rocprofv3 run per pass, counters within the per-block limits).
-# usage: scripts/gpu_pmc_frame.sh <out-prefix> [distance]
+# usage: scripts/gpu_pmc_frame.sh <out-prefix> [distance | stress]
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -499,6 +499,14 @@ constexpr int kRasterThreads = 256, kRasterWaves = kRasterThreads / 64;
 // Small triangles (bounding box within the tile at most 16 x 16 pixels, 32-bit edge functions) are swept four at a time,
 // each by sixteen lanes as 4 x 4 pixel blocks; a wavefront stages this many of them in LDS per round.
 constexpr int kSmallBatch = 32, kSmallBoxPixels = 16;
+// ... and the smallest one per lane: boxes of at most PBR_TINY_AREA pixels, when at least PBR_TINY_MIN_LANES lanes of
+// the wavefront hold one.
+#ifndef PBR_TINY_AREA
+#define PBR_TINY_AREA 32
+#endif
+#ifndef PBR_TINY_MIN_LANES
+#define PBR_TINY_MIN_LANES 16
+#endif
 
 // grid_row: the workgroup's row in its view's grid of (tiles_x, listed_rows + tiles_y) workgroups.
 __device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, const int grid_row, const SetupTri* __restrict__ setup,
@@ -646,12 +654,39 @@ __device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, c
 #else
       const bool small = keep && (tl & 8) && (((box >> 8) & 255) - (box & 255)) < kSmallBoxPixels && ((box >> 24) - ((box >> 16) & 255)) < kSmallBoxPixels;
 #endif
-      const unsigned long long small_mask = __ballot(small);
+      // The smallest of them, one per lane: when a good part of the wavefront holds triangles whose boxes are a few
+      // pixels, every such lane walks its own box pixel by pixel, stepping the three edge functions by their
+      // increments (the same integers as the products: nothing overflows between two pixel centres of the tile).
+      // Sixty-four triangles then cost what the largest box among them costs, about thirty instructions a pixel,
+      // where the groups of sixteen below spend forty and more per triangle.
+      const int box_w = ((box >> 8) & 255) - (box & 255) + 1, box_h = (box >> 24) - ((box >> 16) & 255) + 1;
+      const bool tiny_one = small && box_w * box_h <= PBR_TINY_AREA;
+      const bool tiny = tiny_one && __popcll(__ballot(tiny_one)) >= PBR_TINY_MIN_LANES;
+      if (tiny) {
+        const int bx0 = box & 255, bx1 = (box >> 8) & 255, by1 = box >> 24;
+        int x = bx0, y = (box >> 16) & 255;
+        const int c1 = (tl & 2) ? 0 : -1, c2 = (tl & 4) ? 0 : -1;
+        int r0 = (int)e0 + ((tl & 1) ? 0 : -1) + __mul24(a0, x * 256) + __mul24(b0, y * 256);
+        int r1 = (int)e1 + __mul24(a1, x * 256) + __mul24(b1, y * 256), r2 = (int)e2 + __mul24(a2, x * 256) + __mul24(b2, y * 256);
+        int f0 = r0, f1 = r1, f2 = r2;
+        const uint32_t key_id = id + 1u;
+        for (;;) {
+          if ((f0 | (f1 + c1) | (f2 + c2)) >= 0) {
+            const float l1 = mul_rn((float)f1, inv_area), l2 = mul_rn((float)f2, inv_area);
+            const float z = add_rn(add_rn(z0, mul_rn(l1, dz1)), mul_rn(l2, dz2));
+            atomicMin(&s_key[y * PBR_TILE + x], ((unsigned long long)depth_key(z) << 32) | key_id);
+          }
+          if (x < bx1) { ++x; f0 += a0 * 256; f1 += a1 * 256; f2 += a2 * 256; }
+          else if (y < by1) { ++y; x = bx0; r0 += b0 * 256; r1 += b1 * 256; r2 += b2 * 256; f0 = r0; f1 = r1; f2 = r2; }
+          else break;
+        }
+      }
+      const unsigned long long small_mask = __ballot(small && !tiny);
       if (small_mask) {
         const int n_small = __popcll(small_mask), rank = __popcll(small_mask & ((1ull << lane) - 1ull));
         const int group = lane >> 4, gl = lane & 15, gx = gl & 3, gy = gl >> 2;
         for (int base = 0; base < n_small; base += kSmallBatch) {
-          if (small && rank >= base && rank < base + kSmallBatch) {
+          if (small && !tiny && rank >= base && rank < base + kSmallBatch) {
             uint4* rec = s_tri[wave][rank - base];
             const int c1 = (tl & 2) ? 0 : -1, c2 = (tl & 4) ? 0 : -1;
             rec[0] = make_uint4((uint32_t)((int)e0 + ((tl & 1) ? 0 : -1)), (uint32_t)(int)e1, (uint32_t)(int)e2, (uint32_t)a0);
@@ -701,7 +736,7 @@ __device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, c
           wave_sync();   // the next round overwrites the staging
         }
       }
-      unsigned long long todo = __ballot(keep && !small);
+      unsigned long long todo = __ballot(keep && !small);   // (a tiny triangle is a small one)
       const int lx = lane & 7, ly = lane >> 3;
 #ifdef PBR_SURFACE_TRACE
       if (chunk == 0) { RASTER_TRACE(4, wall_clock64()); RASTER_TRACE(5, (unsigned long long)__popcll(todo)); }
