@@ -200,7 +200,7 @@ int pbr_release_view_buffers(PbrContext* ctx);
 /* pbr_draw_frame_device for callers that cannot allocate device memory: code under HIP graph capture, serving
  * loops that must not touch the allocator, harnesses that forbid hipMalloc.  It has no counterpart in the
  * reference.  Same pass, same result bits, but everything the frame keeps between its launches (append counters,
- * tile bins, set-up triangles, shading records, quad work lists) lives in one fixed array of 26.5 MB that
+ * tile bins, set-up triangles, shading records, quad work lists) lives in one fixed array of 31.2 MB that
  * every GPU the library runs on holds until the process ends, so the call makes no hipMalloc / hipFree and the
  * frame has to fit it: single-sample pipeline only (PBR_E_UNSUPPORTED with bit 16 of sampler_index), at most
  * 2048 tiles of 32 x 32 pixels in rows [y0,y1) (e.g. 1920 x 1080) and at most 32768 triangles over all instances

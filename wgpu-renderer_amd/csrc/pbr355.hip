@@ -36,7 +36,7 @@ constexpr size_t kRecords = align_up(kOverflow + kOverflowCap * sizeof(uint2));
 constexpr size_t kUniform = align_up(kRecords + (size_t)PBR_STATIC_MAX_TRIANGLES * sizeof(TriRecord));
 constexpr size_t kMixedPos = align_up(kUniform + kQuads * sizeof(uint2));
 constexpr size_t kMixedIds = align_up(kMixedPos + kQuads * sizeof(uint32_t));
-constexpr size_t kBytes = align_up(kMixedIds + kQuads * sizeof(uint4));                           // 26.5 MB
+constexpr size_t kBytes = align_up(kMixedIds + kQuads * sizeof(uint4));                           // 31.2 MB
 }  // namespace static_layout
 static __device__ __align__(256) unsigned char scratch[static_layout::kBytes];
 

@@ -13,7 +13,9 @@
 #define PBR_PREFILTER_SAMPLES 1024
 #define PBR_MAX_SHARDS 4096         // most shards the prefilter's texels can be cut into
 #define PBR_LIVE_TILE_CAP 256   // most tiles that the rasteriser starts ahead of the rest (see LiveTiles)
+#ifndef PBR_DENSE_TILE_REFS
 #define PBR_DENSE_TILE_REFS 48   // a tile with more triangle references than this is one of them
+#endif
 #define PBR_BIN_CAP 1024          // triangle references a tile keeps in its own row before spilling to the overflow list
 
 // An rgba8 texture with its mip chain in one allocation.  Every level is stored in blocks of 8 x 4

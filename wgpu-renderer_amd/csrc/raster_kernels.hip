@@ -564,7 +564,11 @@ __device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, c
     clear_count = (s_base[0] >> 30) == parts;
     __syncthreads();   // s_base is used again below
   } else {
-    tile_x = (int)blockIdx.x; tile_y = grid_row - listed_rows;
+    // The rows of tiles are handed out from the middle of the target outwards (a scene's geometry is mostly near it):
+    // workgroups start in grid order, and a tile with triangles that starts behind thousands of background tiles
+    // ends the launch that much later.
+    const int k = grid_row - listed_rows, mid = p->tiles_y >> 1;
+    tile_x = (int)blockIdx.x; tile_y = (k & 1) ? mid - 1 - (k >> 1) : mid + (k >> 1);
     tile = tile_y * p->tiles_x + tile_x;
     n = tile_count[tile] & kCountMask;
     if (n > PBR_DENSE_TILE_REFS) {
