@@ -495,7 +495,7 @@ struct FrameWork {
 #define PBR_SKY_SHARE_SETUP 0.35f
 #endif
 #ifndef PBR_SKY_SHARE_SETUP_ALONE
-#define PBR_SKY_SHARE_SETUP_ALONE 0.55f
+#define PBR_SKY_SHARE_SETUP_ALONE 0.65f
 #endif
 // The share for the passes of several views (pbr_draw_views_device): their launches each fill the chip, and a short
 // set-up launch lets the next pass start under the tail of this one (49.4 / 49.5 / 50.3 / 50.4 / 51.5 / 52.6 / 53.8 us
@@ -615,8 +615,9 @@ static int draw_common(PbrContext* c, const PbrFrameUniforms* u, int W, int H, i
   const int n_tiles = tiles_x * tiles_y;
   // Skybox tiles that ride in the setup launch; the rasteriser's launch shades the rest.  With frames in flight a
   // third is best (52.6 / 52.8 / 53.9 / 54.2 us per 4K frame at 0.35 / 0.45 / 0.55 / 0.65).  A context on its own
-  // wants more than half there: its rasteriser's launch lasts as long as its skybox tiles do, while the set-up launch
-  // waits on its triangles (single frame 78.1 / 76.8 / 76.0 / 76.4 us over the same range).  Measurement builds set
+  // wants two thirds there: its rasteriser's launch lasts as long as its skybox tiles do, while the set-up launch
+  // waits on its triangles (single frame 80.2 / 79.1 / 78.2 / 78.4 us at 0.45 / 0.55 / 0.65 / 0.75, with the rows of
+  // tiles handed out from the middle so that the tiles with triangles no longer end the launch).  Measurement builds set
   // other shares with -DPBR_SKY_SHARE_SETUP=... / -DPBR_SKY_SHARE_SETUP_ALONE=...; the library reads no environment
   // variable.
   const bool alone = c->parent == nullptr && c->children == 0;   // no forks: nothing else of this scene is in flight
