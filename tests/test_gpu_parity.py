@@ -616,6 +616,38 @@ def test_instances_outside_the_frame_are_skipped_without_a_trace():
         r.close()
 
 
+def test_frame_statistics_agree_with_the_visibility_buffer():
+    """The counts a frame reports are gathered from several counters (one group per segment of the quad lists, one count
+    of set-up triangles per group, the pieces of clipped triangles apart): the listed quads against the 2 x 2 quads of
+    the frame's own visibility buffer, the covered pixels against its non-zero entries, and the triangles set up between
+    the triangles seen and the triangles drawn; a second frame reports the same."""
+    pkg = pu._pkg()
+    g = pkg.glTFLoader(); g.load(pkg.renderer.DEFAULT_MODEL)
+    base = g.get_geometries()[0].model
+    models = np.stack([pkg.mathx.mul(pkg.mathx.translate(pkg.mathx.identity(), [(i - 1) * 2.5, (j - 1) * 2.5, 0.0]), base) for j in range(3) for i in range(3)])
+    for kwargs, dolly in (({"width": 640, "height": 360}, 0.0), ({"width": 800, "height": 450, "instance_models": models}, -600.0)):
+        s = pu.SmallScene.build(**kwargs)
+        r = s.renderer
+        try:
+            if dolly:
+                r.camera.update_camera_distance(dolly, 0.0)
+            rgba, vis, st = r.draw_frame(want_vis=True, want_stats=True)
+            h, w = vis.shape
+            q = vis.reshape(h // 2, 2, w // 2, 2).transpose(0, 2, 1, 3).reshape(h // 2, w // 2, 4)
+            any_covered = (q != 0).any(axis=2)
+            uniform = any_covered & (q == q[:, :, :1]).all(axis=2)
+            assert st.uniform_quads == int(uniform.sum()) and st.mixed_quads == int((any_covered & ~uniform).sum()), (st.uniform_quads, st.mixed_quads)
+            assert st.covered_pixels == int((vis != 0).sum())
+            seen = len(np.unique(vis[vis != 0]))
+            drawn = 15452 * (len(models) if "instance_models" in kwargs else 1)
+            assert seen <= st.setup_triangles < drawn, (seen, st.setup_triangles, drawn)
+            _, vis2, st2 = r.draw_frame(want_vis=True, want_stats=True)
+            assert (vis2 == vis).all()
+            assert (st2.uniform_quads, st2.mixed_quads, st2.covered_pixels, st2.setup_triangles) == (st.uniform_quads, st.mixed_quads, st.covered_pixels, st.setup_triangles)
+        finally:
+            r.close()
+
+
 def test_working_buffer_overflow_is_noticed_and_repaired():
     """A camera inside a 3 x 3 grid of helmets (triangles cut by the near plane leave several pieces each), with the
     set-up buffer and the tile-reference list forced far too small: the synchronous entry point enlarges them and
