@@ -702,39 +702,46 @@ __device__ __forceinline__ void raster_tile(const FrameParams* __restrict__ p, c
           const int count = min(kSmallBatch, n_small - base);
           int slot = group;
           bool have = false;
-          int E0n = 0, E1n = 0, E2n = 0, A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0, C1 = 0, C2 = 0, bx0 = 0, bx1 = 0, by1 = 0, bx = 0, by = 0;
+          // f*: the three edge functions at this lane's pixel of the current block, r* at its pixel of the row of
+          // blocks' first block.  They are stepped by four pixels (unsigned arithmetic: a lane beyond the box may run
+          // out of the 32 bits the box's own pixels are known to fit, and its values are never looked at).
+          int A0 = 0, A1 = 0, A2 = 0, B0 = 0, B1 = 0, B2 = 0, C1 = 0, C2 = 0, bx0 = 0, bx1 = 0, by1 = 0, bx = 0, by = 0;
+          uint32_t f0 = 0, f1 = 0, f2 = 0, r0 = 0, r1 = 0, r2 = 0;
           float Z0 = 0, DZ1 = 0, DZ2 = 0, IA = 0;
           uint32_t ID = 0;
           for (;;) {
             if (!have && slot < count) {
               const uint4* rec = s_tri[wave][slot];
-              const uint4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-              E0n = (int)r0.x; E1n = (int)r0.y; E2n = (int)r0.z; A0 = (int)r0.w;
-              A1 = (int)r1.x; A2 = (int)r1.y; B0 = (int)r1.z; B1 = (int)r1.w;
-              B2 = (int)r2.x; Z0 = __uint_as_float(r2.y); DZ1 = __uint_as_float(r2.z); DZ2 = __uint_as_float(r2.w);
-              IA = __uint_as_float(r3.x); ID = r3.y;
-              bx0 = (int)(r3.z & 255u); bx1 = (int)((r3.z >> 8) & 255u); by = (int)((r3.z >> 16) & 255u); by1 = (int)(r3.z >> 24);
-              C1 = -(int)(r3.w & 1u); C2 = -(int)((r3.w >> 1) & 1u);
+              const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3];
+              A0 = (int)q0.w; A1 = (int)q1.x; A2 = (int)q1.y; B0 = (int)q1.z; B1 = (int)q1.w;
+              B2 = (int)q2.x; Z0 = __uint_as_float(q2.y); DZ1 = __uint_as_float(q2.z); DZ2 = __uint_as_float(q2.w);
+              IA = __uint_as_float(q3.x); ID = q3.y;
+              bx0 = (int)(q3.z & 255u); bx1 = (int)((q3.z >> 8) & 255u); by = (int)((q3.z >> 16) & 255u); by1 = (int)(q3.z >> 24);
+              C1 = -(int)(q3.w & 1u); C2 = -(int)((q3.w >> 1) & 1u);
               bx = bx0;
+              const int xs = (bx0 + gx) * 256, ys = (by + gy) * 256;
+              r0 = q0.x + (uint32_t)__mul24(A0, xs) + (uint32_t)__mul24(B0, ys);
+              r1 = q0.y + (uint32_t)__mul24(A1, xs) + (uint32_t)__mul24(B1, ys);
+              r2 = q0.z + (uint32_t)__mul24(A2, xs) + (uint32_t)__mul24(B2, ys);
+              f0 = r0; f1 = r1; f2 = r2;
               slot += 4;
               have = true;
             }
             if (!__ballot(have)) break;
             if (have) {
               const int x = bx + gx, y = by + gy;
-              if (x <= bx1 && y <= by1) {
-                const int xs = x * 256, ys = y * 256;
-                const int f0 = E0n + __mul24(A0, xs) + __mul24(B0, ys);
-                const int f1 = E1n + __mul24(A1, xs) + __mul24(B1, ys);
-                const int f2 = E2n + __mul24(A2, xs) + __mul24(B2, ys);
-                if ((f0 | (f1 + C1) | (f2 + C2)) >= 0) {
-                  const float l1 = mul_rn((float)f1, IA), l2 = mul_rn((float)f2, IA);
-                  const float z = add_rn(add_rn(Z0, mul_rn(l1, DZ1)), mul_rn(l2, DZ2));
-                  atomicMin(&s_key[y * PBR_TILE + x], ((unsigned long long)depth_key(z) << 32) | ID);
-                }
+              if (x <= bx1 && y <= by1 && (int)(f0 | (f1 + (uint32_t)C1) | (f2 + (uint32_t)C2)) >= 0) {
+                const float l1 = mul_rn((float)(int)f1, IA), l2 = mul_rn((float)(int)f2, IA);
+                const float z = add_rn(add_rn(Z0, mul_rn(l1, DZ1)), mul_rn(l2, DZ2));
+                atomicMin(&s_key[y * PBR_TILE + x], ((unsigned long long)depth_key(z) << 32) | ID);
               }
               bx += 4;
-              if (bx > bx1) { bx = bx0; by += 4; have = by <= by1; }
+              if (bx <= bx1) { f0 += (uint32_t)A0 << 10; f1 += (uint32_t)A1 << 10; f2 += (uint32_t)A2 << 10; }
+              else {
+                bx = bx0; by += 4; have = by <= by1;
+                r0 += (uint32_t)B0 << 10; r1 += (uint32_t)B1 << 10; r2 += (uint32_t)B2 << 10;
+                f0 = r0; f1 = r1; f2 = r2;
+              }
             }
           }
           wave_sync();   // the next round overwrites the staging
