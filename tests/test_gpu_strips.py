@@ -109,7 +109,9 @@ def _prefilter_worker(rank, world, port, q):
         # a rank holds nothing of the other ranks' ranges before the exchange
         other = [whole[b:e] for k, (b, e) in enumerate(ranges) if k != rank and e > b]
         nothing_yet = all(not bool(t.any()) for t in other)
-        sent = parallel.all_gather_ranges(whole, ranges, rank, how="p2p")
+        sent = 0
+        for part in sharding.prefilter_pieces(cuts, 2):      # in two parts per rank, as prefilter_sharded sends them
+            sent += parallel.all_gather_ranges(whole, [(16 * b, 16 * e) for b, e in part], rank, how="p2p")
         lib.check(r._ctx, r._lib.pbr_ibl_prefilter(r._ctx, size, mips, 1024, 0, 1))      # the whole map, by this process alone
         alone = np.concatenate([r.download_map(lib.MAP_PREFILTER, m).reshape(-1) for m in range(mips)]).view(np.uint8)
         q.put((rank, nothing_yet, bool((whole.numpy() == alone).all()), sent == ranges[rank][1] - ranges[rank][0], cuts[0] == 6 * size * size))

@@ -269,6 +269,21 @@ def test_prefilter_shards_carry_equal_cost(pkg):
     assert sh.prefilter_cuts(16, 1, 4) == [1536] * 5      # a single level (roughness 0): every rank filters it, nothing is sent
 
 
+def test_prefilter_pieces_tile_every_shard(pkg):
+    """The parts a rank filters and sends one after the other are consecutive, cover its range exactly, and are the same
+    list on every rank (each rank computes it from the cuts alone)."""
+    sh = __import__("wgpu_renderer_amd.sharding", fromlist=["x"])
+    for size, mips, world, pieces in ((2048, 10, 8, 2), (128, 5, 3, 2), (128, 5, 2, 3), (16, 1, 4, 2), (128, 5, 2, 1)):
+        cuts = sh.prefilter_cuts(size, mips, world)
+        parts = sh.prefilter_pieces(cuts, pieces)
+        assert len(parts) == pieces and all(len(p) == world for p in parts)
+        for k in range(world):
+            assert parts[0][k][0] == cuts[k] and parts[-1][k][1] == cuts[k + 1]
+            for j in range(pieces):
+                b, e = parts[j][k]
+                assert b <= e and (j == 0 or parts[j - 1][k][1] == b)
+
+
 def test_prefilter_exchange_carries_only_what_is_worth_sending(pkg):
     """Equal cost is not equal bytes: level 0 is 403 MB of the 2048^2 x 10 map's 537 MB and 0.3 ms of its 15 ms on one
     GPU, so it must not cross a link.  What a rank contributes to the exchange, for both ways of exchanging: at most

@@ -20,14 +20,15 @@ def device_bytes_tensor(ptr, nbytes, device):
     return torch.as_tensor(_DevMem(ptr, nbytes), device=device)
 
 
-def prefilter_sharded(renderer, size, mips, rank=None, world=None, device=None, how="p2p", stream=None, comm_stream=None, rehearse=False):
+def prefilter_sharded(renderer, size, mips, rank=None, world=None, device=None, how="p2p", stream=None, comm_stream=None, rehearse=False, pieces=2):
     """Each rank filters its own range of the levels that are worth sharding, then the ranges are exchanged so that the
     whole map is resident on every GPU (every GPU can shade), and the levels that are cheaper to filter than to send
     (level 0) are filtered by every rank for itself.  With `stream` - the torch stream the renderer's context runs on
-    (Renderer.set_stream) - the exchange runs on a second stream while level 0 is being filtered; without it the steps
-    follow each other (`comm_stream`: the second stream, else one is created and kept).  `rehearse` takes a single rank
-    through the same steps (its range is then the whole map and the exchange has no peer).  Returns the bytes this rank
-    contributed to the exchange; the map lives in the renderer's context."""
+    (Renderer.set_stream) - the exchange runs on a second stream beside the filtering (`comm_stream`: the second
+    stream, else one is created and kept): the rank's range is filtered in `pieces` parts, each part travels while the
+    next is filtered, and the last one while level 0 is; without `stream` the steps follow each other.  `rehearse`
+    takes a single rank through the same steps (its range is then the whole map and the exchange has no peer).
+    Returns the bytes this rank contributed to the exchange; the map lives in the renderer's context."""
     rank = dist.get_rank() if rank is None else rank
     world = dist.get_world_size() if world is None else world
     lib = renderer._lib
@@ -36,34 +37,36 @@ def prefilter_sharded(renderer, size, mips, rank=None, world=None, device=None, 
         _lib.check(ctx, lib.pbr_ibl_prefilter(ctx, size, mips, 1024, 0, 1))
         return 0
     cuts = sharding.prefilter_cuts(size, mips, world)
-    own_first, own_end = cuts[rank], cuts[rank + 1]
-    # this rank's own range first (the call also allocates the map when its size changed) ...
-    _lib.check(ctx, lib.pbr_ibl_prefilter_texels(ctx, size, mips, 1024, own_first, own_end - own_first))
     ptr, total = C.c_void_p(), C.c_size_t()
-    _lib.check(ctx, lib.pbr_ibl_device_ptr(ctx, _lib.MAP_PREFILTER, C.byref(ptr), C.byref(total)))
-    device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-    whole = device_bytes_tensor(ptr.value, total.value, device)
-    ranges = [(16 * b, 16 * e) for b, e in zip(cuts[:-1], cuts[1:])]
-    overlapped = stream is not None and whole.is_cuda
-    if overlapped:
-        # ... its exchange on a second stream, behind an event ...
-        filtered = torch.cuda.Event()
-        filtered.record(stream)
-        comm = comm_stream if comm_stream is not None else _comm_stream(whole.device)
-        comm.wait_event(filtered)
-        with torch.cuda.stream(comm):
-            sent = all_gather_ranges(whole, ranges, rank, how=how)
-            exchanged = torch.cuda.Event()
-            exchanged.record(comm)
-    else:
-        renderer.synchronize()
-        sent = all_gather_ranges(whole, ranges, rank, how=how)
-        if whole.is_cuda:
-            torch.cuda.current_stream(whole.device).synchronize()
-    # ... and meanwhile the leading texels that nobody sends
+    whole, comm, exchanged, sent = None, None, None, 0
+    for part in sharding.prefilter_pieces(cuts, pieces):
+        first, end = part[rank]
+        # this rank's part (the first call also allocates the map when its size changed) ...
+        _lib.check(ctx, lib.pbr_ibl_prefilter_texels(ctx, size, mips, 1024, first, end - first))
+        if whole is None:
+            _lib.check(ctx, lib.pbr_ibl_device_ptr(ctx, _lib.MAP_PREFILTER, C.byref(ptr), C.byref(total)))
+            device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+            whole = device_bytes_tensor(ptr.value, total.value, device)
+        ranges = [(16 * b, 16 * e) for b, e in part]
+        if stream is not None and whole.is_cuda:
+            # ... and its exchange on a second stream, behind an event, while the next part is filtered
+            filtered = torch.cuda.Event()
+            filtered.record(stream)
+            comm = comm if comm is not None else comm_stream if comm_stream is not None else _comm_stream(whole.device)
+            comm.wait_event(filtered)
+            with torch.cuda.stream(comm):
+                sent += all_gather_ranges(whole, ranges, rank, how=how)
+                exchanged = torch.cuda.Event()
+                exchanged.record(comm)
+        else:
+            renderer.synchronize()
+            sent += all_gather_ranges(whole, ranges, rank, how=how)
+            if whole.is_cuda:
+                torch.cuda.current_stream(whole.device).synchronize()
+    # meanwhile the leading texels that nobody sends
     if cuts[0]:
         _lib.check(ctx, lib.pbr_ibl_prefilter_texels(ctx, size, mips, 1024, 0, cuts[0]))
-    if overlapped:
+    if exchanged is not None:
         stream.wait_event(exchanged)     # the renderer's next work on the map follows the exchange
     # the peers wrote through the library's pointer: ask for the map's derived copy to be rebuilt at the next frame
     _lib.check(ctx, lib.pbr_ibl_device_ptr(ctx, _lib.MAP_PREFILTER, C.byref(ptr), C.byref(total)))

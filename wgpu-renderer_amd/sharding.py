@@ -72,3 +72,11 @@ def strip_rows(height, rank, world):
     y0 = 2 * (pairs * rank // world)
     y1 = min(height, 2 * (pairs * (rank + 1) // world))
     return y0, y1
+
+
+def prefilter_pieces(cuts, pieces):
+    """The shards' ranges [cuts[k], cuts[k + 1]) cut once more into `pieces` consecutive parts each: entry j is the
+    list of every rank's j-th part (first texel, end).  A rank filters and sends its parts one after the other, so
+    that all but the last part travel while the next is being filtered (parallel.prefilter_sharded)."""
+    pieces = max(1, int(pieces))
+    return [[(b + (e - b) * j // pieces, b + (e - b) * (j + 1) // pieces) for b, e in zip(cuts[:-1], cuts[1:])] for j in range(pieces)]
