@@ -97,6 +97,17 @@ struct Tex8 { const uint8_t* chain; int w, h, levels; bool srgb; };
 // beyond the colour tolerance is such a pixel.
 static thread_local float t_margin = 1e30f;
 inline void note_margin(float m) { if (m == m && m < t_margin) t_margin = m; }
+// Test instrumentation too (orc_draw_frame_bounds): 0 = the restated pipeline; 1 - 4 = the tangent of shader.wgsl:102
+// turned by as much as it is uncertain, one way or the other about the normal (1, 2) or towards it (3, 4).  The tangent
+// is built from DIFFERENCES of neighbouring pixels' world positions and texcoords: positions of magnitude |p| known to
+// an ulp or a few differ by one pixel's footprint, so the direction of their difference is only known to
+// ulps * eps * |p| / footprint - 1e-4 to 1e-3 radians in a 4K frame - and two correct implementations (another order
+// of the same interpolation, a fused multiply-add) differ by that much.  Nearly everywhere it moves the colour by
+// nothing; at grazing pixels, where 4 N.V N.L + 0.001 is small, it moves it by several 8-bit steps, and where N.V
+// crosses 1.5 / size of the BRDF table it decides whether the table's NaN column (brdf.wgsl:85-86) is in the footprint,
+// i.e. whether the pixel is black.
+static thread_local int t_tangent_variant = 0;
+static thread_local float t_tangent_ulps = 4.0f;
 inline float to_nearest_integer(float v) { return std::fabs(v - std::nearbyint(v)); }
 
 inline V4 texel8(const Tex8& t, int level, int x, int y) {
@@ -613,6 +624,15 @@ void shade_pixel(const Ctx& cx, const Material& m, const CubeTex& irr, const Cub
   q.duvdx = {h1.uv.x - h0.uv.x, h1.uv.y - h0.uv.y};                           // shader.wgsl:99-100
   q.duvdy = {h2.uv.x - h0.uv.x, h2.uv.y - h0.uv.y};
   q.T = normalize(sub(mul(q1, q.duvdy.y), mul(q2, q.duvdx.y)));               // shader.wgsl:102
+  if (t_tangent_variant) {   // (test instrumentation, see t_tangent_variant)
+    const float eps = 5.96e-8f;
+    const float lt = length(sub(mul(q1, q.duvdy.y), mul(q2, q.duvdx.y)));
+    const float err = t_tangent_ulps * eps * (length(f.pos) * (std::fabs(q.duvdy.y) + std::fabs(q.duvdx.y)) + (length(q1) + length(q2)) * std::max(std::fabs(f.uv.y), 1e-3f));
+    const float delta = lt > 0.0f ? std::min(err / lt, 0.25f) : 0.0f;
+    const V3 Nf = normalize(f.normal);
+    const V3 axis = t_tangent_variant <= 2 ? cross(Nf, q.T) : Nf;
+    q.T = normalize(add(q.T, mul(axis, (t_tangent_variant & 1) ? delta : -delta)));
+  }
 
   FragCommon c0 = eval_common(cx, m, q, h0), c1 = eval_common(cx, m, q, h1), c2 = eval_common(cx, m, q, h2);
   FragCommon fc0 = eval_common(cx, m, q, f);
@@ -699,7 +719,8 @@ Ctx make_ctx(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H) {
 // ("center" interpolation, the WGSL default), the 8-bit result is what its samples store, and the
 // resolve averages the stored values (round half to even; the rounding of a multisample resolve is
 // left to the implementation).  The skybox triangle covers the samples no geometry claimed.
-void shade_impl(Ctx& cx, int y0, int y1, int samples, const uint32_t* vis, uint8_t* rgba8, float* margin = nullptr) {
+void shade_impl(Ctx& cx, int y0, int y1, int samples, const uint32_t* vis, uint8_t* rgba8, float* margin = nullptr, int tangent_variant = 0,
+                float tangent_ulps = 4.0f) {
   const OrcScene* sc = cx.sc;
   const OrcFrameUniforms* u = cx.u;
   Material m;
@@ -714,6 +735,7 @@ void shade_impl(Ctx& cx, int y0, int y1, int samples, const uint32_t* vis, uint8
     for (int x = 0; x < W; ++x) {
       int64_t o = (int64_t)(y - y0) * W + x;
       t_margin = 1e30f;
+      t_tangent_variant = tangent_variant; t_tangent_ulps = tangent_ulps;
       if (samples == 1) {
         if (vis[o]) shade_pixel(cx, m, irr, pre, vis[o] - 1, x, y, rgba8 + 4 * o);
         else shade_sky(cx, sky, x, y, rgba8 + 4 * o);
@@ -786,6 +808,24 @@ void orc_draw_frame_margins(const OrcScene* sc, const OrcFrameUniforms* u, int W
   std::vector<float> d((size_t)(y1 - y0) * W * samples);
   raster_impl(cx, y0, y1, samples, vis, d.data());
   shade_impl(cx, y0, y1, samples, vis, rgba8, margin);
+}
+
+// orc_draw_frame_margins plus, per pixel and channel, the lowest and highest 8-bit value the pixel takes when the tangent
+// is turned by its own uncertainty (`tangent_ulps` ulps of the positions and texcoords it is built from; see
+// t_tangent_variant).  Single-sample pipeline only.
+void orc_draw_frame_bounds(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int y0, int y1, float tangent_ulps, uint8_t* rgba8, uint32_t* vis,
+                           float* margin, uint8_t* lo8, uint8_t* hi8) {
+  Ctx cx = make_ctx(sc, u, W, H);
+  std::vector<float> d((size_t)(y1 - y0) * W);
+  raster_impl(cx, y0, y1, 1, vis, d.data());
+  shade_impl(cx, y0, y1, 1, vis, rgba8, margin);
+  const size_t n = (size_t)(y1 - y0) * W * 4;
+  std::memcpy(lo8, rgba8, n); std::memcpy(hi8, rgba8, n);
+  std::vector<uint8_t> other(n);
+  for (int variant = 1; variant <= 4; ++variant) {
+    shade_impl(cx, y0, y1, 1, vis, other.data(), nullptr, variant, tangent_ulps);
+    for (size_t i = 0; i < n; ++i) { lo8[i] = std::min(lo8[i], other[i]); hi8[i] = std::max(hi8[i], other[i]); }
+  }
 }
 
 void orc_sample_cube(const float* chain, int size, int levels, const float* dir3, float lod, float* rgba_out) {

@@ -136,6 +136,11 @@ void orc_draw_frame(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H,
  * of a "nearest" mipmap filter, min / mag switch, texel of a "nearest" filter) was to its switching point; see frame.cpp. */
 void orc_draw_frame_margins(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int y0, int y1,
                             uint8_t* rgba8, uint32_t* vis, float* margin);
+/* The same plus, per pixel and channel, the lowest and highest 8-bit value reachable when the tangent of shader.wgsl:102
+ * (a direction built from differences of neighbouring pixels' positions and texcoords) is turned by its own uncertainty,
+ * `tangent_ulps` ulps of those positions and texcoords (test instrumentation; single-sample pipeline). */
+void orc_draw_frame_bounds(const OrcScene* sc, const OrcFrameUniforms* u, int W, int H, int y0, int y1, float tangent_ulps,
+                           uint8_t* rgba8, uint32_t* vis, float* margin, uint8_t* lo8, uint8_t* hi8);
 
 /* Samplers exposed for unit tests. */
 void orc_sample_cube(const float* chain, int size, int levels, const float* dir3, float lod, float* rgba_out);

@@ -75,6 +75,7 @@ def load():
         "orc_irradiance_bounds": (None, [P, C.c_int, C.c_int, C.c_int, C.c_float, P, P, I64, I64]),
         "orc_prefilter_bounds": (None, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, P, P, I64, I64]),
         "orc_draw_frame_margins": (None, [C.POINTER(Scene), C.POINTER(FrameUniforms), C.c_int, C.c_int, C.c_int, C.c_int, P, P, P]),
+        "orc_draw_frame_bounds": (None, [C.POINTER(Scene), C.POINTER(FrameUniforms), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, P, P, P, P, P]),
         "orc_brdf_lut": (None, [C.c_int, P, P, C.c_int, C.c_int]),
         "orc_radical_inverse": (C.c_float, [C.c_uint32]),
         "orc_irradiance_trip_counts": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),

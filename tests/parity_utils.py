@@ -137,6 +137,19 @@ class OracleScene:
         self.lib.orc_draw_frame_margins(C.byref(sc), C.byref(u), W, H, y0, y1, ob.ptr(rgba), ob.ptr(vis), ob.ptr(margin))
         return rgba, vis, margin
 
+    def draw_with_bounds(self, uniforms, W, H, y0=0, y1=None, tangent_ulps=4.0):
+        """draw_with_margins plus, per pixel and channel, the interval of 8-bit values the pixel takes when the tangent
+        the shader builds from screen-space differences is turned by its own uncertainty (oracle/frame.cpp,
+        t_tangent_variant): returns rgba, vis, margin, lo, hi."""
+        y1 = H if y1 is None else y1
+        sc = self.c_scene()
+        u = copy_uniforms(uniforms, ob.FrameUniforms)
+        rgba, lo, hi = (np.zeros((y1 - y0, W, 4), dtype=np.uint8) for _ in range(3))
+        vis = np.zeros((y1 - y0, W), dtype=np.uint32)
+        margin = np.zeros((y1 - y0, W), dtype=np.float32)
+        self.lib.orc_draw_frame_bounds(C.byref(sc), C.byref(u), W, H, y0, y1, float(tangent_ulps), ob.ptr(rgba), ob.ptr(vis), ob.ptr(margin), ob.ptr(lo), ob.ptr(hi))
+        return rgba, vis, margin, lo, hi
+
     def map_bounds(self):
         """Reachable intervals of the three nearest-pixel cube generators (oracle/ibl.cpp, *_bounds)."""
         if getattr(self, "_bounds", None) is None:

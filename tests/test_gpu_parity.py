@@ -519,10 +519,83 @@ def test_4k_frame_properties(refsize):
         refsize.width, refsize.height = 1280, 720
 
 
+def assert_whole_frame(rgba, vis, oracle_result, name, share=1e-4, unexplained=0):
+    """Every pixel of a frame against the oracle's: the visibility buffer bit for bit; the colour within 2/255 of the
+    interval the oracle's pixel sweeps when the shader's screen-space tangent is turned by its own uncertainty (four
+    ulps of the positions and texcoords whose differences it is built from: OracleScene.draw_with_bounds) - an interval
+    that is a single value for all but a few hundred pixels of a 4K frame - or else a pixel whose discrete sampling
+    decision sat on its switching point; and the pixels that need either allowance are few.  `unexplained`: how many
+    pixels may differ with neither explanation (0 for the benchmark's frames)."""
+    orgba, ovis, margin, lo, hi = oracle_result
+    assert (vis == ovis).all(), f"{name}: {int((vis != ovis).sum())} pixels show another triangle"
+    g = rgba.astype(np.int32)
+    outside = ((g < lo.astype(np.int32) - 2) | (g > hi.astype(np.int32) + 2)).any(-1)
+    beyond = np.abs(g - orgba.astype(np.int32)).max(-1) > 2
+    print(f"{name}: {int(beyond.sum())} of {beyond.size} pixels beyond 2/255 of the oracle's frame, {int(outside.sum())} of them outside the tangent's interval, "
+          f"{int((outside & (margin >= LOD_SLACK)).sum())} of those with no sampling decision near its switching point")
+    assert int((outside & (margin >= LOD_SLACK)).sum()) <= unexplained, f"{name}: pixels differ with nothing to explain it, e.g. {np.argwhere(outside & (margin >= LOD_SLACK))[:4].tolist()}"
+    assert beyond.mean() <= share, f"{name}: {int(beyond.sum())} pixels beyond 2/255"
+    assert pu.psnr(rgba, orgba) >= 45.0 and (rgba[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("turns", [0, 90, 180, 270])
+def test_4k_whole_frames_of_the_orbit_against_the_oracle(refsize, turns):
+    """Whole 3840x2160 frames of the benchmark's orbit (front, one side, back, other side), every row, shaded by both
+    sides from the device's maps: see assert_whole_frame."""
+    r = refsize.renderer
+    cam0 = r.camera
+    r.width, r.height = 3840, 2160
+    refsize.width, refsize.height = 3840, 2160
+    try:
+        r.camera = refsize.pkg.Camera()
+        for _ in range(turns):
+            r.camera.update_camera_rotation(-10.0, 0.0)
+        u = r.frame_uniforms()
+        rgba, vis = r.draw_frame(want_vis=True)
+        with refsize.oracle.with_maps(refsize.gpu_maps()):
+            result = refsize.oracle.draw_with_bounds(u, 3840, 2160)
+        assert 0.05 < (result[1] > 0).mean() < 0.15
+        assert_whole_frame(rgba, vis, result, f"whole 4K frame {turns}")
+    finally:
+        r.camera = cam0
+        r.width, r.height = 1280, 720
+        refsize.width, refsize.height = 1280, 720
+
+
+def test_stress_scene_whole_frame_against_the_oracle():
+    """The benchmark's stress scene at its own size - ten by ten helmets, 1.5 million triangles of a few pixels each,
+    7680x4320 - every pixel against the oracle (assert_whole_frame): the rasteriser's paths for small triangles, tiles
+    with hundreds of references, the segmented quad lists and counters at the scale they were built for; and its eight
+    strips compose the same frame."""
+    import bench
+    pkg = pu._pkg()
+    g = pkg.glTFLoader(); g.load(pkg.renderer.DEFAULT_MODEL)
+    models = bench.stress_instances(pkg, g.get_geometries()[0].model)
+    s = pu.SmallScene.build(width=7680, height=4320, instance_models=models)
+    r = s.renderer
+    try:
+        r.camera.update_camera_distance((5.0 - 30.0) * 100.0, 0.0)
+        u = r.frame_uniforms()
+        rgba, vis, st = r.draw_frame(want_vis=True, want_stats=True)
+        assert st.binned_refs == 0 and st.setup_triangles > 800000 and 0.2 < st.covered_pixels / vis.size < 0.3
+        result = s.oracle.draw_with_bounds(u, 7680, 4320)
+        # Sixteen of the 33 million pixels may differ beyond what the tangent's uncertainty and the sampling decisions
+        # explain (eight do): highlights of near-mirror texels on triangles of a few pixels, 3 - 9 steps in one channel,
+        # and one pixel where a singular specular term is +inf on one side (white) and 0/0 on the other (black).
+        assert_whole_frame(rgba, vis, result, "stress scene, 7680x4320", unexplained=16)
+        sharding = __import__("wgpu_renderer_amd.sharding", fromlist=["x"])
+        for k in (0, 3, 7):
+            y0, y1 = sharding.strip_rows(4320, k, 8)
+            band, bvis = r.draw_frame(y0=y0, y1=y1, want_vis=True)
+            assert (band == rgba[y0:y1]).all() and (bvis == vis[y0:y1]).all(), k
+    finally:
+        r.close()
+
+
 def test_4k_late_orbit_frame_drawn_as_a_view_of_a_pass(refsize):
     """Frame 180 of the benchmark's orbit (the back of the helmet) at 3840x2160, drawn the way the benchmark draws it:
-    as the last of the four views of one pbr_draw_views_device pass (frames 177..180).  A band of rows through the
-    helmet against the oracle, which shades from the device's own maps."""
+    as the last of the four views of one pbr_draw_views_device pass (frames 177..180).  The first and the last view,
+    every pixel, against the oracle, which shades from the device's own maps (assert_whole_frame)."""
     import torch
     r = refsize.renderer
     cam0 = r.camera
@@ -540,23 +613,19 @@ def test_4k_late_orbit_frame_drawn_as_a_view_of_a_pass(refsize):
         torch.cuda.synchronize()   # the fills run on torch's stream, the pass on the library's
         r.draw_views_device(us, [o.data_ptr() for o in outs])
         r.synchronize()
-        rgba = outs[3].cpu().numpy()
-        y0, y1 = 900, 980
-        with refsize.oracle.with_maps(refsize.gpu_maps()):
-            orgba, ovis, margin = refsize.oracle.draw_with_margins(us[3], 3840, 2160, y0, y1)
-        assert 0.05 < (ovis > 0).mean() < 0.6
-        d = np.abs(rgba[y0:y1].astype(np.int32) - orgba.astype(np.int32)).max(-1)
-        far = d > 2
-        print(f"4K frame 180 band: {int(far.sum())} of {d.size} pixels beyond 2/255 (max {int(d.max())})")
-        assert (margin[far] < LOD_SLACK).all() and far.mean() <= 1e-3
-        assert pu.psnr(rgba[y0:y1], orgba) >= 45.0 and (rgba[..., 3] == 255).all()
-        # the view's visibility: the same frame drawn alone gives the same bytes, and its visibility buffer is the oracle's
+        # every view's visibility: the same frame drawn alone gives the same bytes as the view of the pass, and a visibility buffer
         single = torch.zeros((2160, 3840, 4), dtype=torch.uint8, device="cuda:0")
-        vis = torch.zeros((2160, 3840), dtype=torch.int32, device="cuda:0")
-        torch.cuda.synchronize()
-        r.draw_frame_device(single.data_ptr(), d_vis=vis.data_ptr(), uniforms=us[3])
-        r.synchronize()
-        assert (single.cpu().numpy() == rgba).all() and (vis[y0:y1].cpu().numpy().view(np.uint32) == ovis).all()
+        dvis = torch.zeros((2160, 3840), dtype=torch.int32, device="cuda:0")
+        for v in (0, 3):
+            torch.cuda.synchronize()
+            r.draw_frame_device(single.data_ptr(), d_vis=dvis.data_ptr(), uniforms=us[v])
+            r.synchronize()
+            rgba = outs[v].cpu().numpy()
+            assert (single.cpu().numpy() == rgba).all()
+            with refsize.oracle.with_maps(refsize.gpu_maps()):
+                result = refsize.oracle.draw_with_bounds(us[v], 3840, 2160)
+            assert 0.05 < (result[1] > 0).mean() < 0.15
+            assert_whole_frame(rgba, dvis.cpu().numpy().view(np.uint32), result, f"4K frame {177 + v} as view {v} of a pass")
         r.release_view_buffers()
         r.draw_views_device(us, [o.data_ptr() for o in outs])     # the buffers come back at the next pass
         r.synchronize()
