@@ -137,7 +137,7 @@ class OracleScene:
         self.lib.orc_draw_frame_margins(C.byref(sc), C.byref(u), W, H, y0, y1, ob.ptr(rgba), ob.ptr(vis), ob.ptr(margin))
         return rgba, vis, margin
 
-    def draw_with_bounds(self, uniforms, W, H, y0=0, y1=None, tangent_ulps=4.0):
+    def draw_with_bounds(self, uniforms, W, H, y0=0, y1=None, tangent_ulps=8.0):
         """draw_with_margins plus, per pixel and channel, the interval of 8-bit values the pixel takes when the tangent
         the shader builds from screen-space differences is turned by its own uncertainty (oracle/frame.cpp,
         t_tangent_variant): returns rgba, vis, margin, lo, hi."""

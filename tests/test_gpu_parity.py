@@ -521,9 +521,9 @@ def test_4k_frame_properties(refsize):
 
 def assert_whole_frame(rgba, vis, oracle_result, name, share=1e-4, unexplained=0):
     """Every pixel of a frame against the oracle's: the visibility buffer bit for bit; the colour within 2/255 of the
-    interval the oracle's pixel sweeps when the shader's screen-space tangent is turned by its own uncertainty (four
+    interval the oracle's pixel sweeps when the shader's screen-space tangent is turned by its own uncertainty (eight
     ulps of the positions and texcoords whose differences it is built from: OracleScene.draw_with_bounds) - an interval
-    that is a single value for all but a few hundred pixels of a 4K frame - or else a pixel whose discrete sampling
+    that is a single value for all but a few thousand pixels of a 4K frame - or else a pixel whose discrete sampling
     decision sat on its switching point; and the pixels that need either allowance are few.  `unexplained`: how many
     pixels may differ with neither explanation (0 for the benchmark's frames)."""
     orgba, ovis, margin, lo, hi = oracle_result
@@ -538,9 +538,9 @@ def assert_whole_frame(rgba, vis, oracle_result, name, share=1e-4, unexplained=0
     assert pu.psnr(rgba, orgba) >= 45.0 and (rgba[..., 3] == 255).all()
 
 
-@pytest.mark.parametrize("turns", [0, 90, 180, 270])
+@pytest.mark.parametrize("turns", [0, 45, 90, 135, 180, 225, 270, 315])
 def test_4k_whole_frames_of_the_orbit_against_the_oracle(refsize, turns):
-    """Whole 3840x2160 frames of the benchmark's orbit (front, one side, back, other side), every row, shaded by both
+    """Whole 3840x2160 frames of the benchmark's orbit (every 45 degrees), every row, shaded by both
     sides from the device's maps: see assert_whole_frame."""
     r = refsize.renderer
     cam0 = r.camera
@@ -558,6 +558,25 @@ def test_4k_whole_frames_of_the_orbit_against_the_oracle(refsize, turns):
         assert_whole_frame(rgba, vis, result, f"whole 4K frame {turns}")
     finally:
         r.camera = cam0
+        r.width, r.height = 1280, 720
+        refsize.width, refsize.height = 1280, 720
+
+
+def test_4k_multisampled_whole_frame_against_the_oracle(refsize):
+    """The 4x multisampled pipeline at 3840x2160, every pixel: the four visibility entries per pixel bit for bit, the
+    resolved colour to the bar of the small multisampled frames."""
+    r = refsize.renderer
+    r.width, r.height = 3840, 2160
+    refsize.width, refsize.height = 3840, 2160
+    try:
+        r.msaa_options["enable"] = True
+        rgba, vis = r.draw_frame(want_vis=True)
+        with refsize.oracle.with_maps(refsize.gpu_maps()):
+            orgba, ovis, margin = refsize.render_oracle_with_margins()
+        assert vis.shape == (2160, 3840, 4) and (vis == ovis).all()
+        assert_frame_close(rgba, orgba, vis, ovis, "4K multisampled frame", margin, slack=4 * LOD_SLACK)
+    finally:
+        r.msaa_options["enable"] = False
         r.width, r.height = 1280, 720
         refsize.width, refsize.height = 1280, 720
 
@@ -580,7 +599,7 @@ def test_stress_scene_whole_frame_against_the_oracle():
         assert st.binned_refs == 0 and st.setup_triangles > 800000 and 0.2 < st.covered_pixels / vis.size < 0.3
         result = s.oracle.draw_with_bounds(u, 7680, 4320)
         # Sixteen of the 33 million pixels may differ beyond what the tangent's uncertainty and the sampling decisions
-        # explain (eight do): highlights of near-mirror texels on triangles of a few pixels, 3 - 9 steps in one channel,
+        # explain (six do): highlights of near-mirror texels on triangles of a few pixels, 3 - 9 steps in one channel,
         # and one pixel where a singular specular term is +inf on one side (white) and 0/0 on the other (black).
         assert_whole_frame(rgba, vis, result, "stress scene, 7680x4320", unexplained=16)
         sharding = __import__("wgpu_renderer_amd.sharding", fromlist=["x"])
