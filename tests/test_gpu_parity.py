@@ -562,6 +562,28 @@ def test_4k_whole_frames_of_the_orbit_against_the_oracle(refsize, turns):
         refsize.width, refsize.height = 1280, 720
 
 
+@pytest.mark.parametrize("sampler_index", [0, 6, 9])
+def test_4k_whole_frame_with_another_sampler(refsize, sampler_index):
+    """The general surface kernel (any sampler but the reference's default) at 3840x2160, every pixel: nearest / nearest
+    with clamped addresses, nearest minification under linear magnification, and the reverse."""
+    r = refsize.renderer
+    r.width, r.height = 3840, 2160
+    refsize.width, refsize.height = 3840, 2160
+    r.texture_options.update(addressModeU="repeat" if sampler_index & 1 else "clamp-to-edge", addressModeV="repeat" if sampler_index & 2 else "clamp-to-edge",
+                             magFilter="linear" if sampler_index & 4 else "nearest", minFilter="linear" if sampler_index & 8 else "nearest")
+    try:
+        u = r.frame_uniforms()
+        assert u.sampler_index == sampler_index
+        rgba, vis = r.draw_frame(want_vis=True)
+        with refsize.oracle.with_maps(refsize.gpu_maps()):
+            result = refsize.oracle.draw_with_bounds(u, 3840, 2160)
+        assert_whole_frame(rgba, vis, result, f"whole 4K frame, sampler {sampler_index}", share=1e-3)
+    finally:
+        r.texture_options.update(addressModeU="repeat", addressModeV="repeat", magFilter="linear", minFilter="linear")
+        r.width, r.height = 1280, 720
+        refsize.width, refsize.height = 1280, 720
+
+
 def test_4k_multisampled_whole_frame_against_the_oracle(refsize):
     """The 4x multisampled pipeline at 3840x2160, every pixel: the four visibility entries per pixel bit for bit, the
     resolved colour to the bar of the small multisampled frames."""
