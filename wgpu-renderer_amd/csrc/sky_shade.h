@@ -128,6 +128,17 @@ PBR_DEV void pack_color_pair(V3 c0, V3 c1, uint32_t& out0, uint32_t& out1) {
 #pragma clang fp contract(fast)
   // 255 c^(1/2.2) = exp2(log2(c) / 2.2 + log2(255)): one multiply-add per channel pair between the two transcendentals
   const float g = 1.0f / 2.2f, k = 7.994353436858858f;
+#ifdef PBR_ABLATE_SKY_GAMMA
+  {   // measurement build only (wrong colours): what the twelve transcendentals per pixel pair cost the frame - 0.8 us of 49
+
+    uint32_t p0 = 0xff000000u, p1 = 0xff000000u;
+    p0 = __builtin_amdgcn_cvt_pk_u8_f32(c0.x * 255.0f, 0u, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(c1.x * 255.0f, 0u, p1);
+    p0 = __builtin_amdgcn_cvt_pk_u8_f32(c0.y * 255.0f, 1u, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(c1.y * 255.0f, 1u, p1);
+    p0 = __builtin_amdgcn_cvt_pk_u8_f32(c0.z * 255.0f, 2u, p0); p1 = __builtin_amdgcn_cvt_pk_u8_f32(c1.z * 255.0f, 2u, p1);
+    out0 = p0; out1 = p1;
+    return;
+  }
+#endif
   const f2 lx = (f2){log2_fast(c0.x), log2_fast(c1.x)} * g + k, ly = (f2){log2_fast(c0.y), log2_fast(c1.y)} * g + k, lz = (f2){log2_fast(c0.z), log2_fast(c1.z)} * g + k;
   const f2 ex = {exp2_fast(lx.x), exp2_fast(lx.y)}, ey = {exp2_fast(ly.x), exp2_fast(ly.y)}, ez = {exp2_fast(lz.x), exp2_fast(lz.y)};
   uint32_t p0 = 0xff000000u, p1 = 0xff000000u;
