@@ -882,7 +882,9 @@ def test_prefilter_shards_compose(small):
 
 
 def test_large_prefilter_spot_checks():
-    """The large prefilter configuration (2048^2 cube, 10 mips, 1024 samples): full-size GPU run, oracle on sampled texel ranges."""
+    """The large prefilter configuration (2048^2 cube, 10 mips, 1024 samples), filtered at full size on the GPU: levels
+    3 to 9 (524 000 texels) against the oracle texel for texel, the three largest levels on sampled ranges of 8 192
+    texels (the oracle filters 170 000 texels a second on the test box)."""
     pkg = pu._pkg()
     lib = pkg._lib
     hdr = pkg.synthetic_sky(4096, 2048)
@@ -896,13 +898,13 @@ def test_large_prefilter_spot_checks():
     chain, levels = ob.mip_chain_rgba32f(data, hdr.width, hdr.height)
     rng = np.random.default_rng(9)
     try:
-        for m in (0, 1, 3, 6, 9):
+        for m in range(mips):
             s = size >> m
             got = r.download_map(lib.MAP_PREFILTER, m)
             assert np.isfinite(got).all() and (got[..., 3] == 1).all()
             n = 6 * s * s
-            count = min(256, n)
-            for first in sorted(set(int(x) for x in rng.integers(0, n - count + 1, size=3))):
+            count = n if m >= 3 else 8192
+            for first in ([0] if m >= 3 else sorted(set(int(x) for x in rng.integers(0, n - count + 1, size=3)))):
                 rough = np.float32(m / (mips - 1))
                 ref = ob.prefilter_level(chain, hdr.width, hdr.height, levels, s, rough, first, count)
                 lo, hi = ob.prefilter_level_bounds(chain, hdr.width, hdr.height, levels, s, rough, first=first, count=count)
