@@ -685,7 +685,12 @@ PBR_DEV void surface_fast_quad(const FrameParams* __restrict__ p, const ResolveI
   // (one 16-byte load per tap from the interleaved copy of the five textures)
   uint32_t t_nrm[4], t_orm[4], t_alb[4], t_emi[4], t_h0[4], t_h1[4], t_h2[4];
   {
+#ifdef PBR_ABLATE_ATLAS_TAPS
+    // measurement build only (wrong colours): no loads, the addresses kept alive
+    const uint4 m0 = make_uint4(fp.o00, fp.o10, 0x80808080u, fp.o11), m1 = m0, m2 = m0, m3 = m0;
+#else
     const uint4 m0 = in.atlas[fp.o00], m1 = in.atlas[fp.o10], m2 = in.atlas[fp.o01], m3 = in.atlas[fp.o11];
+#endif
     t_alb[0] = m0.x; t_alb[1] = m1.x; t_alb[2] = m2.x; t_alb[3] = m3.x;
     t_emi[0] = m0.y; t_emi[1] = m1.y; t_emi[2] = m2.y; t_emi[3] = m3.y;
     t_nrm[0] = m0.z; t_nrm[1] = m1.z; t_nrm[2] = m2.z; t_nrm[3] = m3.z;

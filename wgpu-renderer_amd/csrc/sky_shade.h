@@ -63,7 +63,13 @@ PBR_DEV CubeFoot cube_foot(const DevCubeRgb& bordered, int level, const CubeCoor
 struct Rgb { float x, y, z; };   // one texel of a DevCubeRgb: 12 bytes, fetched with one three-dword load
 PBR_DEV void cube_load4(const float* base, const CubeFoot& f, Rgb t[4]) {
   const Rgb* q = reinterpret_cast<const Rgb*>(base) + f.o;
+#ifdef PBR_ABLATE_IBL_TAPS
+  // measurement build only (wrong colours): no loads, the address kept alive
+  const float fake = __uint_as_float(((uint32_t)(size_t)q & 0x3fffffu) | 0x3e000000u);
+  t[0] = Rgb{fake, fake, fake}; t[1] = t[0]; t[2] = t[0]; t[3] = t[0];
+#else
   t[0] = q[0]; t[1] = q[1]; t[2] = q[f.m]; t[3] = q[f.m + 1];
+#endif
 }
 
 
