@@ -127,8 +127,8 @@ def valu_issue(kernels, ms):
 
 
 def prefilter_counters(path=None):
-    """The counters of the prefilter's dominant launch shape (the 1024-thread instantiation: levels 1 to 3 of the
-    2048^2 map, nine tenths of the time) from the committed rocprofv3 summary, per launch: vector instructions, the
+    """The counters of the prefilter's dominant launch (the 1024-thread shape: levels 0 to 2 of the 2048^2 map in
+    one launch, nine tenths of the time) from the committed rocprofv3 summary, per launch: vector instructions, the
     graphics-active cycles (summed over the eight XCDs by the profiler) and the texture-address units' busy cycles
     (summed over the 256 units).  Derived: the share of the vector issue slots the launch used at the clock it actually
     ran at, and the share of time the texture-address units were busy.  None if the file is missing or has another
@@ -138,7 +138,7 @@ def prefilter_counters(path=None):
         with open(path or PREFILTER_COUNTER_FILE) as f:
             for line in f:
                 if " dispatches " in line:
-                    kernel = "1024" if "1024>" in line else "other"
+                    kernel = "1024" if "1024>" in line or "prefilter_levels_kernel" in line else "other"   # (the large levels share one launch)
                     continue
                 parts = line.split()
                 if kernel and len(parts) >= 2 and parts[0][:1].isupper() and "_" in parts[0]:

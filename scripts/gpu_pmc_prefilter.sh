@@ -15,7 +15,7 @@ run TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum GRBM_GUI_AC
 timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/scripts/gpu_prefilter_only.py > /dev/null 2>&1
 cd $R
 {
-  for d in $OUT/pass*; do python scripts/pmc_summary.py $(ls $d/*/*counter_collection.csv) "prefilter_kernel<1"; done
+  for d in $OUT/pass*; do python scripts/pmc_summary.py $(ls $d/*/*counter_collection.csv) "prefilter_kernel<1" "prefilter_levels_kernel"; done
   grep -h prefilter $OUT/trace/*/*kernel_stats.csv
 } > $OUT/summary.txt
 cat $OUT/summary.txt

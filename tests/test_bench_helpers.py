@@ -108,8 +108,8 @@ def test_prefilter_roofline_reproduces_from_the_committed_counters():
         shape = None
         for line in f:
             if " dispatches " in line:
-                shape = "1024>" in line
-            elif shape and len(line.split()) >= 2:
+                shape = "1024>" in line or "prefilter_levels_kernel" in line
+            elif shape and len(line.split()) >= 2 and line.split()[0][:1].isupper() and "_" in line.split()[0]:   # (counter lines; the summary ends with kernel-trace rows)
                 table.setdefault(line.split()[0], float(line.split()[1]))
     cycles = table["GRBM_GUI_ACTIVE"] / 8                       # the profiler sums the eight XCDs' counters
     assert abs(c["ta_busy_frac"] - table["TA_TA_BUSY_sum"] / 256 / cycles) < 1e-12

@@ -193,10 +193,10 @@ PBR_DEV int clamp_to(int x, int top) {
   return r;
 }
 
-template <int SPLIT, bool POW2, int THREADS = 256>
-__global__ void __launch_bounds__(THREADS)
-prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples, int n_single, float total_weight, float4* __restrict__ out, int size,
-                 long long first, long long count) {
+// (block: the workgroup's number within its level's launch, or within its level's part of a launch of several levels)
+template <int SPLIT, bool POW2, int THREADS>
+__device__ __forceinline__ void prefilter_block(const DevEquirect& hdr, const PrefilterSample* __restrict__ samples, int n_samples, int n_single, float total_weight,
+                                                float4* __restrict__ out, int size, long long first, long long count, unsigned block) {
   constexpr int kThreads = THREADS;
   // per sample {lx, ly, lz, wa}, {kx, cx, ky, cy}: the pixel coordinates in source level l0 are theta * kx + cx and
   // asin(y) * ky + cy, i.e. (angle * scale + 0.5) * size of equirectangular.wgsl:68-69 with the size multiplied in (for
@@ -213,7 +213,7 @@ prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, i
     }
     __syncthreads();
   }
-  const long long gid = (long long)blockIdx.x * kThreads + threadIdx.x;
+  const long long gid = (long long)block * kThreads + threadIdx.x;
   long long t;
   int sub;
   bool live;
@@ -355,6 +355,37 @@ prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, i
   if (live && sub == 0) out[t] = make_float4(r / total_weight, g / total_weight, b / total_weight, 1.0f);
 }
 
+template <int SPLIT, bool POW2, int THREADS = 256>
+__global__ void __launch_bounds__(THREADS)
+prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, int n_samples, int n_single, float total_weight, float4* __restrict__ out, int size,
+                 long long first, long long count) {
+  prefilter_block<SPLIT, POW2, THREADS>(hdr, samples, n_samples, n_single, total_weight, out, size, first, count, blockIdx.x);
+}
+
+// The large levels of a call (a million texels and more: the one-texel-per-lane variant in its wide shape) in one
+// launch.  A launch ends with its last wavefronts' chains of a thousand samples running on a chip that is emptying, about
+// a third of a millisecond per large level, and the next level's launch waits for it.  In one launch a level's
+// workgroups take the places the level before it frees; the levels come dearest first and roughness 0 (one sample per
+// texel) last, where it fills the tail: 13.05 -> 12.2 ms for the 2048^2 x 10 map.  A texel's arithmetic is what it is
+// in a launch of its level alone.  (All ten levels in one launch, the small ones through their own lane splits in the
+// same kernel, ran as long as ten launches: the kernel that holds all three variants is slower in its main loop, and
+// the small levels gain nothing from sharing a launch - the 128^2 x 5 map took 0.39 ms against 0.36.)
+struct PrefilterLevelJob {
+  const PrefilterSample* samples; int n_samples, n_single; float total_weight;
+  float4* out; int size; long long first, count;
+  unsigned first_block;   // the launch's workgroups from here on (up to the next job's) are this level's
+};
+constexpr int kPrefilterMaxJobs = 4;
+struct PrefilterLevelJobs { int n; PrefilterLevelJob job[kPrefilterMaxJobs]; };
+
+template <bool POW2>
+__global__ void __launch_bounds__(kPrefilterWideThreads) prefilter_levels_kernel(DevEquirect hdr, PrefilterLevelJobs jobs) {
+  int k = 0;
+  while (k + 1 < jobs.n && blockIdx.x >= jobs.job[k + 1].first_block) ++k;
+  const PrefilterLevelJob& j = jobs.job[k];
+  prefilter_block<1, POW2, kPrefilterWideThreads>(hdr, j.samples, j.n_samples, j.n_single, j.total_weight, j.out, j.size, j.first, j.count, blockIdx.x - j.first_block);
+}
+
 // One workgroup covers 256 texels of one LUT row; the row's roughness fixes the half-vector table,
 // which is built once in LDS and then read as a broadcast by every lane.
 __global__ void __launch_bounds__(256) brdf_lut_kernel(uint16_t* __restrict__ out, int size) {
@@ -470,6 +501,45 @@ void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* sam
     else hipLaunchKernelGGL((prefilter_kernel<64, false>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, hdr, samples, n_samples, 0, total_weight,
                             out_level, level_size, (long long)first, (long long)count);
   }
+}
+
+void launch_prefilter_levels(hipStream_t s, DevEquirect hdr, const PrefilterLevelRun* runs, int n_runs) {
+  const bool pow2 = (hdr.w & (hdr.w - 1)) == 0 && (hdr.h & (hdr.h - 1)) == 0 && hdr.w >= hdr.h;
+  // the levels that take the wide one-texel-per-lane shape share a launch; every other level has a launch of its own
+  std::vector<const PrefilterLevelRun*> wide;
+  for (int i = 0; i < n_runs; ++i) {
+    const PrefilterLevelRun& r = runs[i];
+    if (r.count <= 0) continue;
+#ifdef PBR_PREFILTER_NO_MERGE
+    const bool shares = false;   // measurement builds: a launch per level
+#else
+    const bool shares = 6ll * r.level_size * r.level_size >= (1 << 20);
+#endif
+    if (shares) wide.push_back(&r);
+    else launch_prefilter(s, hdr, r.samples, r.n_samples, r.n_single, r.total_weight, r.out_level, r.level_size, r.first, r.count);
+  }
+  if (wide.size() < 2 || wide.size() > (size_t)kPrefilterMaxJobs) {
+    for (const PrefilterLevelRun* r : wide) launch_prefilter(s, hdr, r->samples, r->n_samples, r->n_single, r->total_weight, r->out_level, r->level_size, r->first, r->count);
+    return;
+  }
+  // dearest first; a level of one sample per texel (roughness 0) last
+  std::stable_sort(wide.begin(), wide.end(), [](const PrefilterLevelRun* a, const PrefilterLevelRun* b) {
+    const bool a_last = a->n_samples <= 1, b_last = b->n_samples <= 1;
+    if (a_last != b_last) return b_last;
+    return a->count * (double)a->n_samples > b->count * (double)b->n_samples;
+  });
+  PrefilterLevelJobs jobs = {};
+  unsigned blocks = 0;
+  for (const PrefilterLevelRun* r : wide) {
+    PrefilterLevelJob& j = jobs.job[jobs.n++];
+    j.samples = r->samples; j.n_samples = r->n_samples; j.n_single = r->n_single; j.total_weight = r->total_weight;
+    j.out = r->out_level; j.size = r->level_size; j.first = r->first; j.count = r->count; j.first_block = blocks;
+    const long long row0 = (r->first / r->level_size) & ~7ll, row1 = (r->first + r->count - 1) / r->level_size;
+    const long long threads = ((row1 - row0) / 8 + 1) * ((r->level_size + 7) / 8) * 64;
+    blocks += (unsigned)((threads + kPrefilterWideThreads - 1) / kPrefilterWideThreads);
+  }
+  if (pow2) hipLaunchKernelGGL(prefilter_levels_kernel<true>, dim3(blocks), dim3(kPrefilterWideThreads), 0, s, hdr, jobs);
+  else hipLaunchKernelGGL(prefilter_levels_kernel<false>, dim3(blocks), dim3(kPrefilterWideThreads), 0, s, hdr, jobs);
 }
 
 void launch_brdf_lut(hipStream_t s, uint16_t* out, int size) {

@@ -1077,15 +1077,18 @@ static int prefilter_texel_range(PbrContext* c, int32_t size, int32_t mips, int3
   } else if (begin > end || end > c->pre_total_texels) {
     return fail(c, PBR_E_ARG, "texel range [%llu, %llu) outside the map's %zu texels", (unsigned long long)begin, (unsigned long long)end, c->pre_total_texels);
   }
+  PrefilterLevelRun runs[PBR_MAX_LEVELS];
+  int n_runs = 0;
   for (int m = 0; m < mips; ++m) {
     const size_t s = (size_t)std::max(1, size >> m);
     const size_t lo = c->pre.off[m], hi = lo + 6 * s * s;
     // the levels in front of the shards' ranges are filtered whole by every shard (prefilter_cuts)
     const size_t a = hi <= (size_t)replicated ? lo : std::max(lo, (size_t)begin), b = hi <= (size_t)replicated ? hi : std::min(hi, (size_t)end);
     if (a >= b) continue;
-    launch_prefilter(c->stream, c->hdr, c->d_samples + (size_t)m * PBR_PREFILTER_SAMPLES, pr->table_count[m], pr->table_single[m], pr->table_weight[m],
-                     c->d_pre + lo, (int)s, (int64_t)(a - lo), (int64_t)(b - a));
+    runs[n_runs++] = PrefilterLevelRun{c->d_samples + (size_t)m * PBR_PREFILTER_SAMPLES, pr->table_count[m], pr->table_single[m], pr->table_weight[m],
+                                       c->d_pre + lo, (int)s, (int64_t)(a - lo), (int64_t)(b - a)};
   }
+  launch_prefilter_levels(c->stream, c->hdr, runs, n_runs);
   pr->pre_b.dirty = true;
   HIP_TRY(c, hipGetLastError());
   return PBR_OK;

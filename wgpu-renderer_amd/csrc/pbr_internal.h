@@ -209,6 +209,9 @@ void launch_irradiance(hipStream_t s, DevEquirect hdr, const float* tables, int 
 // n_single: the leading samples of the table that read one source level (see build_prefilter_table)
 void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* samples, int n_samples, int n_single, float inv_weight,
                       float4* out_level, int level_size, int64_t first, int64_t count);
+// one level's part of a prefilter call; launch_prefilter_levels puts the large levels of a call into one launch
+struct PrefilterLevelRun { const PrefilterSample* samples; int n_samples, n_single; float total_weight; float4* out_level; int level_size; int64_t first, count; };
+void launch_prefilter_levels(hipStream_t s, DevEquirect hdr, const PrefilterLevelRun* runs, int n_runs);
 void launch_brdf_lut(hipStream_t s, uint16_t* out, int size);
 
 struct SkyShare;   // sky_shade.h
