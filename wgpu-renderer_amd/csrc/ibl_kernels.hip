@@ -362,7 +362,7 @@ prefilter_kernel(DevEquirect hdr, const PrefilterSample* __restrict__ samples, i
   prefilter_block<SPLIT, POW2, THREADS>(hdr, samples, n_samples, n_single, total_weight, out, size, first, count, blockIdx.x);
 }
 
-// The large levels of a call (a million texels and more: the one-texel-per-lane variant in its wide shape) in one
+// The large levels of a call (262 144 texels and more: the one-texel-per-lane variant, all in its wide shape) in one
 // launch.  A launch ends with its last wavefronts' chains of a thousand samples running on a chip that is emptying, about
 // a third of a millisecond per large level, and the next level's launch waits for it.  In one launch a level's
 // workgroups take the places the level before it frees; the levels come dearest first and roughness 0 (one sample per
@@ -375,7 +375,7 @@ struct PrefilterLevelJob {
   float4* out; int size; long long first, count;
   unsigned first_block;   // the launch's workgroups from here on (up to the next job's) are this level's
 };
-constexpr int kPrefilterMaxJobs = 4;
+constexpr int kPrefilterMaxJobs = 8;
 struct PrefilterLevelJobs { int n; PrefilterLevelJob job[kPrefilterMaxJobs]; };
 
 template <bool POW2>
@@ -505,7 +505,7 @@ void launch_prefilter(hipStream_t s, DevEquirect hdr, const PrefilterSample* sam
 
 void launch_prefilter_levels(hipStream_t s, DevEquirect hdr, const PrefilterLevelRun* runs, int n_runs) {
   const bool pow2 = (hdr.w & (hdr.w - 1)) == 0 && (hdr.h & (hdr.h - 1)) == 0 && hdr.w >= hdr.h;
-  // the levels that take the wide one-texel-per-lane shape share a launch; every other level has a launch of its own
+  // the levels that take the one-texel-per-lane variant share a launch (in its wide shape); every other level has a launch of its own
   std::vector<const PrefilterLevelRun*> wide;
   for (int i = 0; i < n_runs; ++i) {
     const PrefilterLevelRun& r = runs[i];
@@ -513,7 +513,10 @@ void launch_prefilter_levels(hipStream_t s, DevEquirect hdr, const PrefilterLeve
 #ifdef PBR_PREFILTER_NO_MERGE
     const bool shares = false;   // measurement builds: a launch per level
 #else
-    const bool shares = 6ll * r.level_size * r.level_size >= (1 << 20);
+#ifndef PBR_PREFILTER_SHARE_LOG2
+#define PBR_PREFILTER_SHARE_LOG2 18   // every level that takes the one-texel-per-lane variant (12.3 -> 12.0 ms against sharing from a million texels)
+#endif
+    const bool shares = 6ll * r.level_size * r.level_size >= (1ll << PBR_PREFILTER_SHARE_LOG2);
 #endif
     if (shares) wide.push_back(&r);
     else launch_prefilter(s, hdr, r.samples, r.n_samples, r.n_single, r.total_weight, r.out_level, r.level_size, r.first, r.count);
