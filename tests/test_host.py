@@ -223,8 +223,8 @@ def kept_samples_f64(roughness, n=1024):
 def test_prefilter_shards_carry_equal_cost(pkg):
     """The shards of the large prefilter (2048^2, 10 levels) must be balanced in work, not in texels: level 0 is three
     quarters of the texels and, at roughness 0, one sample each.  Cost model: kept samples per texel (counted here
-    in float64 independently of the library) times the per-sample factors measured on MI355X for the +-Y faces and
-    the rougher levels, for the lane split of the small levels and for the floor of a launch
+    in float64 independently of the library) times the per-sample factors measured on MI355X for the +-Y faces (their
+    middle rows, around the poles, apart) and the rougher levels, for the lane split of the small levels and for the floor of a launch
     (profiles/r03_prefilter_shards.json)."""
     sh = __import__("wgpu_renderer_amd.sharding", fromlist=["x"])
     size, mips = 2048, 10
@@ -232,21 +232,25 @@ def test_prefilter_shards_carry_equal_cost(pkg):
     lib_kept = sh.prefilter_kept_samples(mips)
     assert lib_kept[0] == 1 and all(abs(a - b) <= 2 for a, b in zip(kept, lib_kept)), (kept, lib_kept)
 
-    def texel_cost(m, face):   # the library's cost model restated: picoseconds per texel
+    def texel_cost(m, face, middle):   # the library's cost model restated: picoseconds per texel
         r = m / (mips - 1)
         level_texels = 6 * (size >> m) ** 2
         pole = face in (2, 3)
-        scatter = (1.45 if pole else 1.0) if r <= 0.17 else (2.55 if pole else 1.47) if r <= 0.28 else (1.70 if pole else 1.60)
+        scatter = ((2.71 if middle else 1.03) if pole else 1.0) if r <= 0.17 else ((4.70 if middle else 1.25) if pole else 1.22) if r <= 0.28 else (1.41 if pole else 1.33)
         shape = 1.0 if level_texels >= 1 << 18 else 1.85 if level_texels >= 1 << 14 else 1.60
         return (kept[m] + 8) * 1.22 * scatter * shape + 8.5e6 / level_texels
 
-    segments = []     # (first texel, texel count, cost per texel, samples per texel) of every face of every level
+    # (first texel, texel count, cost per texel, samples per texel) of the three row parts of every face of every level:
+    # the rows in front of the face's middle quarter, the middle quarter (on the +-Y faces: around the pole), the rest
+    segments = []
     first = 0
     for m in range(mips):
-        n = (size >> m) ** 2
+        s = size >> m
+        rows = (s * 3 // 8, s * 5 // 8 - s * 3 // 8, s - s * 5 // 8)
         for face in range(6):
-            segments.append((first, n, texel_cost(m, face), kept[m]))
-            first += n
+            for part in range(3):
+                segments.append((first, rows[part] * s, texel_cost(m, face, part == 1), kept[m]))
+                first += rows[part] * s
     total_texels = first
 
     def load(b, e, column):

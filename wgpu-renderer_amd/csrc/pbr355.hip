@@ -214,15 +214,24 @@ void prefilter_costs(int mips, PrefilterCost* pc) {
   }
   cached = *pc; cached_mips = mips;
 }
-// picoseconds per texel of face f of level m
-uint64_t prefilter_texel_cost(const PrefilterCost& pc, int size, int mips, int m, int f) {
+// picoseconds per texel of face f of level m; `part` 0 - 2: the rows of the face in front of its middle quarter, the middle
+// quarter, and the rows behind it.  On the +-Y faces the middle rows look at the poles, where the samples of
+// neighbouring texels fan out over all longitudes of the equirectangular image: timed in bands of rows, those two
+// eighths of a pole face cost 1.7 times the other six, which cost what a side face costs; with a pole face 1.45 (1.73
+// at the next level) times a side face in all, that puts its middle quarter at 2.7 (3.8) side faces' rate.
+uint64_t prefilter_texel_cost(const PrefilterCost& pc, int size, int mips, int m, int f, int part) {
   const float roughness = prefilter_roughness(m, mips);
   const uint64_t s = (uint64_t)std::max(1, size >> m), level_texels = 6 * s * s;
   if (roughness == 0.0f) return 10 + 8500000 / level_texels;   // a copy of the source pixel
-  const bool pole = f == 2 || f == 3;
-  const uint64_t scatter = roughness <= 0.17f ? (pole ? 145 : 100) : roughness <= 0.28f ? (pole ? 255 : 147) : (pole ? 170 : 160);   // hundredths
+  const bool pole = f == 2 || f == 3, middle = part == 1;
+  const uint64_t scatter = roughness <= 0.17f ? (pole ? (middle ? 271 : 103) : 100) : roughness <= 0.28f ? (pole ? (middle ? 470 : 125) : 122) : (pole ? 141 : 133);   // hundredths
   const uint64_t shape = level_texels >= (1u << 18) ? 100 : level_texels >= (1u << 14) ? 185 : 160;
   return ((uint64_t)pc.kept[m] + PREFILTER_TEXEL_OVERHEAD) * 122 * scatter * shape / 1000000 + 8500000 / level_texels;
+}
+// texels of part `part` of a face of s x s texels (rows [0, 3s/8), [3s/8, 5s/8), [5s/8, s))
+uint64_t prefilter_part_texels(uint64_t s, int part) {
+  const uint64_t r0 = s * 3 / 8, r1 = s * 5 / 8;
+  return (part == 0 ? r0 : part == 1 ? r1 - r0 : s - r1) * s;
 }
 
 // A level whose texels take less time to filter than to send is not worth sharding: every shard filters it for itself
@@ -251,7 +260,7 @@ void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
   for (int m = 0; m < mips; ++m) {
     const uint64_t s = (uint64_t)std::max(1, size >> m);
     if (m < first_level) replicated_texels += 6 * s * s;
-    else for (int f = 0; f < 6; ++f) total_cost += s * s * prefilter_texel_cost(pc, size, mips, m, f);
+    else for (int f = 0; f < 6; ++f) for (int part = 0; part < 3; ++part) total_cost += prefilter_part_texels(s, part) * prefilter_texel_cost(pc, size, mips, m, f, part);
     total_texels += 6 * s * s;
   }
   cuts[0] = replicated_texels; cuts[n] = total_texels;
@@ -260,12 +269,15 @@ void prefilter_cuts(int size, int mips, int n, uint64_t* cuts) {
     uint64_t before_cost = 0, before_texels = replicated_texels;
     bool placed = false;
     for (int m = first_level; m < mips && !placed; ++m) {
-      const uint64_t s = (uint64_t)std::max(1, size >> m), face_texels = s * s;
-      for (int f = 0; f < 6 && !placed; ++f) {
-        const uint64_t per_texel = prefilter_texel_cost(pc, size, mips, m, f), c = face_texels * per_texel;
-        if (before_cost + c > target) { cuts[k] = before_texels + (target - before_cost) / per_texel; placed = true; }
-        else { before_cost += c; before_texels += face_texels; }
-      }
+      const uint64_t s = (uint64_t)std::max(1, size >> m);
+      for (int f = 0; f < 6 && !placed; ++f)
+        for (int part = 0; part < 3 && !placed; ++part) {
+          const uint64_t part_texels = prefilter_part_texels(s, part);
+          if (part_texels == 0) continue;
+          const uint64_t per_texel = prefilter_texel_cost(pc, size, mips, m, f, part), c = part_texels * per_texel;
+          if (before_cost + c > target) { cuts[k] = before_texels + (target - before_cost) / per_texel; placed = true; }
+          else { before_cost += c; before_texels += part_texels; }
+        }
     }
     if (!placed) cuts[k] = total_texels;
   }
