@@ -153,8 +153,8 @@ int pbr_ibl_prefilter_shard_range(PbrContext* ctx, int32_t shard_index, int32_t 
  * 0 for a single shard.  Shard k owns texels [cuts[k], cuts[k + 1]), cuts[shard_count] being the texel count of
  * the whole map; the ranges have equal cost.  A texel of level m weighs the number of the 1024 GGX samples that
  * contribute at that level's roughness (those with N.L > 0, prefiltermap.wgsl:138) plus a small constant for the
- * per-texel work; a sample of the +-Y faces and of the rougher levels weighs more by factors measured on MI355X
- * (its source pixels are scattered over more cache lines).  Host arithmetic only: needs neither a context nor a
+ * per-texel work; a sample of the +-Y faces - most of all of their middle rows, which look at the poles - and of the
+ * rougher levels weighs more by factors measured on MI355X (its source pixels are scattered over more cache lines).  Host arithmetic only: needs neither a context nor a
  * device. */
 int pbr_ibl_prefilter_partition(int32_t size, int32_t mips, int32_t shard_count, uint64_t* cuts);
 /* Number of the 1024 samples of prefiltermap.wgsl:131-168 that contribute (N.L > 0) at level `level` of `mips`
