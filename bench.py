@@ -496,7 +496,7 @@ def run_orbit(args, pkg, torch, dist, ctxinfo):
                                 "frac": raster_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(raster_name), "algorithmic_bytes": raster_bytes, "views_per_launch": V,
                                 "note": "the pass's second launch, alone on the chip: tile rasteriser plus the skybox colour of the tiles the set-up launch did not take; "
                                         "as long as the surface launch, so the frame has two dominant kernels",
-                                "bound_measured": "vector issue of the skybox arithmetic (62 instructions per pixel) and its 16 twelve-byte taps per thread; the tiles with geometry wait on their per-triangle loops",
+                                "bound_measured": "vector issue of the skybox arithmetic (62 instructions per pixel) and its 8 sixteen-byte loads per thread; the tiles with geometry wait on their per-triangle loops",
                                 "valu_issue": valu_issue(["raster_kernel"], raster_ms / V)},
             "kernel_ms_alone_per_pass": {"setup": kern_ms[0], "raster": kern_ms[1], "surface": kern_ms[2]},
             "frame_roofline": {"bound": "hbm", "kernels": "all kernels of one frame (setup + sky, raster + sky, surface); wall time per frame with the configured frames in flight",

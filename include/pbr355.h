@@ -170,7 +170,10 @@ int pbr_ibl_prefilter_kept_samples(int32_t mips, int32_t level, int32_t* kept);
  * (renderer.ts:243-259, :492-501, :1951-1954): coverage and depth per sample at the standard sample
  * points, each triangle of a pixel shaded once at the pixel centre, the target resolved to the
  * average of the four samples.  vis_out / d_vis then hold four uint32 per pixel (sample order) and
- * pbr_debug_depth four floats per pixel. */
+ * pbr_debug_depth four floats per pixel.
+ * Arithmetic: f32 throughout, as the shaders', except the skybox's bilinear taps (skybox.wgsl:28), which are taken
+ * from a copy of the cube in halves with weights in halves: at most one 8-bit step from the f32 blend, on a few per
+ * cent of the skybox's pixels. */
 int pbr_draw_frame(PbrContext* ctx, const PbrFrameUniforms* u, int32_t w, int32_t h, int32_t y0, int32_t y1,
                    uint8_t* rgba8_out, uint32_t* vis_out, PbrFrameStats* stats);
 /* Same pass with outputs left in device memory (d_vis may be NULL); returns without synchronising

@@ -383,7 +383,7 @@ struct PbrContextPrivate {
   uint32_t frames_drawn = 0;
   // Bordered copies of the cube maps for the resolve: every face carries the adjoining texels of its
   // neighbours (and the three-texel mean at corners), so a bilinear lookup never leaves its face.
-  struct Bordered { float* d = nullptr; DevCubeRgb cube = {}; bool dirty = true; };
+  struct Bordered { float* d = nullptr; uint4* d_pairs = nullptr; DevCubeRgb cube = {}; bool dirty = true; };
   Bordered sky_b, irr_b, pre_b;
   uint4* d_lut_quad = nullptr; int lut_quad_size = 0; bool lut_quad_dirty = true;   // footprint copy of the BRDF table for the resolve (ResolveInputs::lut_quad)
   uint4* d_atlas = nullptr; size_t atlas_texels = 0; bool atlas_dirty = true;       // interleaved copy of five equally sized material textures (ResolveInputs::atlas)
@@ -423,11 +423,12 @@ static int check_sticky(PbrContext* c) {
   return PBR_OK;
 }
 
-static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const DevCube& src) {
+static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const DevCube& src, bool with_pairs = false) {
   if (!b.dirty && b.d) return PBR_OK;
   if (!b.d || b.cube.size != src.size || b.cube.levels != src.levels) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (b.d) { (void)hipFree(b.d); b.d = nullptr; }
+    if (b.d_pairs) { (void)hipFree(b.d_pairs); b.d_pairs = nullptr; b.cube.pairs = nullptr; }
     size_t total = 0;
     for (int l = 0; l < src.levels; ++l) {
       const size_t n = (size_t)std::max(1, src.size >> l);
@@ -437,8 +438,14 @@ static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const
     if (total > 0xffffffffull) return fail(c, PBR_E_ARG, "cube map too large");
     HIP_TRY(c, hipMalloc(&b.d, total * 3 * sizeof(float)));
     b.cube.base = b.d; b.cube.size = src.size; b.cube.levels = src.levels;
+    if (with_pairs) {
+      const size_t m = (size_t)std::max(1, src.size) + 2;
+      HIP_TRY(c, hipMalloc(&b.d_pairs, 6 * m * m * sizeof(uint4)));
+      b.cube.pairs = b.d_pairs;
+    }
   }
   for (int l = 0; l < src.levels; ++l) launch_cube_border(c->stream, src, l, b.d + 3 * (size_t)b.cube.off[l]);
+  if (with_pairs) launch_cube_pairs(c->stream, b.d + 3 * (size_t)b.cube.off[0], b.d_pairs, src.size);
   b.dirty = false;
   return PBR_OK;
 }
@@ -449,7 +456,7 @@ static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const
 // event recorded behind it (wait_for_lookup_copies), whether they triggered the rebuild or the owner's own first frame did.
 static int refresh_lookup_copies(PbrContext* c, PbrContext* a, PbrContextPrivate* apr, bool one_size) {
   int rc = PBR_OK;
-  if ((rc = refresh_bordered(a, apr->sky_b, a->sky)) || (rc = refresh_bordered(a, apr->irr_b, a->irr)) || (rc = refresh_bordered(a, apr->pre_b, a->pre))) return rc;
+  if ((rc = refresh_bordered(a, apr->sky_b, a->sky, true)) || (rc = refresh_bordered(a, apr->irr_b, a->irr)) || (rc = refresh_bordered(a, apr->pre_b, a->pre))) return rc;
   if (apr->lut_quad_dirty || apr->lut_quad_size != a->lut_size) {
     if (apr->lut_quad_size != a->lut_size) {
       HIP_TRY(c, hipStreamSynchronize(a->stream));
@@ -793,7 +800,7 @@ int pbr_destroy(PbrContext* c) {
   free_dev(c->d_vsoa); free_dev(c->d_indices); free_dev(c->d_inst_model); free_dev(c->d_inst_normal);
   for (auto& t : c->d_tex) free_dev(t);
   free_dev(c->d_hdr); free_dev(c->d_hdr_rgb); free_dev(c->d_sky); free_dev(c->d_irr); free_dev(c->d_pre); free_dev(c->d_lut);
-  { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); free_dev(pr->d_lut_quad); free_dev(pr->d_atlas); }
+  { PbrContextPrivate* pr = priv_of(c); free_dev(pr->sky_b.d); free_dev(pr->sky_b.d_pairs); free_dev(pr->irr_b.d); free_dev(pr->pre_b.d); free_dev(pr->d_lut_quad); free_dev(pr->d_atlas); }
   free_dev(c->d_samples); free_dev(c->d_irr_tables);
   free_dev(c->d_vout); free_dev(c->d_setup); free_dev(c->d_records); free_dev(c->d_tile_count); free_dev(c->d_live_info); free_dev(c->d_live_tiles); free_dev(c->d_tile_live); free_dev(c->d_bins); free_dev(c->quad_lists.uniform); free_dev(c->quad_lists.mixed_pos); free_dev(c->quad_lists.mixed_ids);
   free_dev(c->d_overflow); free_dev(c->d_counters); free_dev(c->d_vis); free_dev(c->d_depth); free_dev(c->d_color);

@@ -48,6 +48,10 @@ struct DevCubeRgb {
   const float* base;              // three floats per texel
   uint32_t off[PBR_MAX_LEVELS];   // texel offset of each level
   int32_t size, levels;           // size of level 0 without the border
+  // Level 0 once more for the skybox pass (null for the other maps), in halves and by pairs: entry i of a row holds
+  // texels i and i + 1 of that row as (r r' | g g' | b b' | unused), so a bilinear lookup is two 16-byte loads, one
+  // per row, and each channel of a row one v_dot2_f32_f16 against the row's two weights.
+  const uint4* pairs;
 };
 
 
@@ -279,6 +283,7 @@ void launch_surface_msaa(hipStream_t s, const FrameParams& p, const ResolveInput
                          uint8_t* rgba8, int W, int rows, bool fast);
 int surface_fast_blocks_per_cu();
 void launch_cube_border(hipStream_t s, DevCube src, int level, float* dst_level);   // dst: [6][n+2][n+2][3]
+void launch_cube_pairs(hipStream_t s, const float* bordered_level0, uint4* pairs, int size);   // DevCubeRgb::pairs from level 0 of the bordered copy
 void launch_lut_quad(hipStream_t s, const uint16_t* lut_rgba16f, uint4* quad, int size);
 // interleaves five texture chains of `texels` texels each (slot order of PBR_TEX_*) into the layout of ResolveInputs::atlas
 void launch_material_atlas(hipStream_t s, const uint32_t* const chains[5], uint4* atlas, size_t texels);

@@ -1043,6 +1043,25 @@ __global__ void __launch_bounds__(256) cube_border_kernel(DevCube src, int level
   dst[3 * (size_t)idx] = out.x; dst[3 * (size_t)idx + 1] = out.y; dst[3 * (size_t)idx + 2] = out.z;
 }
 
+// DevCubeRgb::pairs: level 0 of a bordered cube in halves, every entry the texel and its right-hand neighbour.  Finite
+// values beyond the largest half (65504, far above anything the 8-bit target distinguishes from white) are clamped to
+// it; infinities and NaNs stay what they are.
+__global__ void __launch_bounds__(256) cube_pairs_kernel(const float* __restrict__ rgb, uint4* __restrict__ pairs, int m) {
+  const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= 6u * m * m) return;
+  const bool last = idx % (uint32_t)m == (uint32_t)(m - 1);      // the last column starts no footprint; it repeats itself
+  const float* a = rgb + 3 * (size_t)idx;
+  const float* b = last ? a : a + 3;
+  auto half_bits = [](float v) -> uint32_t {
+    const float lim = 65504.0f;
+    if (fabsf(v) <= 3.0e38f) v = fminf(fmaxf(v, -lim), lim);
+    const _Float16 h = (_Float16)v;      // round to nearest even
+    uint16_t bits; __builtin_memcpy(&bits, &h, 2);
+    return bits;
+  };
+  pairs[idx] = make_uint4(half_bits(a[0]) | half_bits(b[0]) << 16, half_bits(a[1]) | half_bits(b[1]) << 16, half_bits(a[2]) | half_bits(b[2]) << 16, 0u);
+}
+
 // The two channels fs_main reads from the rgba16f BRDF table (shader.wgsl:150-151), packed for the resolve: per texel
 // the whole bilinear footprint that starts there (see ResolveInputs::lut_quad).
 __global__ void __launch_bounds__(256) lut_quad_kernel(const uint16_t* __restrict__ lut, uint4* __restrict__ quad, int size) {
@@ -1151,6 +1170,11 @@ void launch_material_atlas(hipStream_t s, const uint32_t* const chains[5], uint4
 void launch_cube_border(hipStream_t s, DevCube src, int level, float* dst_level) {
   const int n = std::max(1, src.size >> level), m = n + 2;
   hipLaunchKernelGGL(cube_border_kernel, dim3((unsigned)((6u * m * m + 255u) / 256u)), dim3(256), 0, s, src, level, dst_level);
+}
+
+void launch_cube_pairs(hipStream_t s, const float* bordered_level0, uint4* pairs, int size) {
+  const int m = std::max(1, size) + 2;
+  hipLaunchKernelGGL(cube_pairs_kernel, dim3((unsigned)((6u * m * m + 255u) / 256u)), dim3(256), 0, s, bordered_level0, pairs, m);
 }
 
 void launch_count_covered(hipStream_t s, const uint32_t* vis, size_t n, int samples, uint32_t* covered) {

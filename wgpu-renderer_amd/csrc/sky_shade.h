@@ -94,7 +94,7 @@ PBR_DEV void cube_face_coords(int face, V3 d, float& sc, float& tc, float& rc) {
 // pixels.  Each element goes through exactly the operations of the one-pixel functions above.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-struct CubeFootPair { uint32_t o[2]; uint32_t m; f2 w[4]; };   // element k of each weight belongs to the pixel with offset o[k]
+struct CubeFootPair { uint32_t o[2]; uint32_t m; f2 w[4]; };   // element k of each weight belongs to the pixel with offset o[k] (counted from level 0)
 
 // cube_foot on level 0 for two lookups at once (faces and face coordinates given per element).
 PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int face1, f2 sc, f2 tc, f2 rc) {
@@ -114,19 +114,25 @@ PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int f
   f.w[0] = oma * omb; f.w[1] = a * omb; f.w[2] = oma * b; f.w[3] = a * b;
   const int i0 = (int)tu.x, j0 = (int)tv.x, i1 = (int)tu.y, j1 = (int)tv.y;
   // texel index with 24-bit multiply-adds (face * m + row and m are far below 2^24 for any cube the library accepts)
-  f.o[0] = bordered.off[0] + __umul24(__umul24((uint32_t)face0, (uint32_t)m) + (uint32_t)j0, (uint32_t)m) + (uint32_t)i0;
-  f.o[1] = bordered.off[0] + __umul24(__umul24((uint32_t)face1, (uint32_t)m) + (uint32_t)j1, (uint32_t)m) + (uint32_t)i1;
+  f.o[0] = __umul24(__umul24((uint32_t)face0, (uint32_t)m) + (uint32_t)j0, (uint32_t)m) + (uint32_t)i0;
+  f.o[1] = __umul24(__umul24((uint32_t)face1, (uint32_t)m) + (uint32_t)j1, (uint32_t)m) + (uint32_t)i1;
   f.m = (uint32_t)m;
   return f;
 }
 
-// weigh4 for pixel E of a pair: red and green as one two-wide chain, blue alone.
+// One bilinear lookup of pixel E of a pair from the paired copy of the cube (DevCubeRgb::pairs): `top` and `bottom`
+// are the entries at the footprint's two rows, each holding the row's two texels channel by channel, so a channel is
+// two v_dot2_f32_f16 (products and sums in f32) against the rows' weights rounded to halves.  Texels and weights carry
+// eleven significant bits: the colour moves by up to a thousandth of itself, a tenth of an 8-bit step after the gamma
+// curve, so about one pixel in ten lands on the neighbouring 8-bit value and none moves further.
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 template <int E>
-PBR_DEV V3 weigh4_of_pair(const Rgb t[4], const f2 w[4]) {
-#pragma clang fp contract(fast)
-  const f2 rg = (((f2){t[0].x, t[0].y} * w[0][E] + (f2){t[1].x, t[1].y} * w[1][E]) + (f2){t[2].x, t[2].y} * w[2][E]) + (f2){t[3].x, t[3].y} * w[3][E];
-  const float bl = ((t[0].z * w[0][E] + t[1].z * w[1][E]) + t[2].z * w[2][E]) + t[3].z * w[3][E];
-  return v3(rg.x, rg.y, bl);
+PBR_DEV V3 weigh_pairs(const uint4& top, const uint4& bottom, const f2 w[4]) {
+  const h2 wt = __builtin_convertvector((f2){w[0][E], w[1][E]}, h2), wb = __builtin_convertvector((f2){w[2][E], w[3][E]}, h2);
+  auto halves = [](uint32_t v) { h2 r; __builtin_memcpy(&r, &v, 4); return r; };
+  return v3(__builtin_amdgcn_fdot2(halves(top.x), wt, __builtin_amdgcn_fdot2(halves(bottom.x), wb, 0.0f, false), false),
+            __builtin_amdgcn_fdot2(halves(top.y), wt, __builtin_amdgcn_fdot2(halves(bottom.y), wb, 0.0f, false), false),
+            __builtin_amdgcn_fdot2(halves(top.z), wt, __builtin_amdgcn_fdot2(halves(bottom.z), wb, 0.0f, false), false));
 }
 
 // pack_color for two pixels: the two multiplies of each channel run two-wide.
@@ -164,8 +170,8 @@ PBR_DEV void store_colour4(uint32_t* dst, const uint32_t c[4]) {
 }
 
 // Skybox colour of four horizontally adjacent pixels (x0 .. x0+3, y): the clip-space position is
-// unprojected with the inverse view-projection matrix and the bordered cube sampled bilinearly; all
-// sixteen taps are issued before any is used.  The unprojected direction is affine in x, so the
+// unprojected with the inverse view-projection matrix and the bordered cube sampled bilinearly from its
+// paired copy; all eight loads are issued before any is used.  The unprojected direction is affine in x, so the
 // cube face is selected once, for the first pixel, and the face coordinates of the other three are
 // that pixel's plus a constant step; when the group straddles a face edge (or w changes sign in
 // it) the other three take the full selection again.
@@ -213,26 +219,25 @@ PBR_DEV void sky_pixels4(const FrameParams* __restrict__ p, const DevCubeRgb& sk
     sc23 = (f2){c[2].sc, c[3].sc}; tc23 = (f2){c[2].tc, c[3].tc}; rc23 = (f2){c[2].rc, c[3].rc};
   }
   const CubeFootPair fa = cube_foot_pair(sky, face[0], face[1], sc01, tc01, rc01), fb = cube_foot_pair(sky, face[2], face[3], sc23, tc23, rc23);
-  Rgb tap[4][4];
-  const Rgb* base = reinterpret_cast<const Rgb*>(sky.base);
-  // bytes from a texel to the one below it: the same for every lane; taken through readfirstlane so that it stays one
+  uint4 top[4], bottom[4];
+  // bytes from an entry to the one below it: the same for every lane; taken through readfirstlane so that it stays one
   // scalar that is added rather than multiplied out again per lane
-  const size_t pitch = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fa.m * (uint32_t)sizeof(Rgb)));
+  const size_t pitch = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(fa.m * (uint32_t)sizeof(uint4)));
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const CubeFootPair& f = k < 2 ? fa : fb;
-    const Rgb* q = base + f.o[k & 1];
-    const Rgb* below = reinterpret_cast<const Rgb*>(reinterpret_cast<const char*>(q) + pitch);
+    const uint4* q = sky.pairs + f.o[k & 1];
+    const uint4* below = reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(q) + pitch);
 #ifdef PBR_ABLATE_SKY_TAPS
-    // measurement build only (wrong colours): no loads, the addresses kept alive - the sixteen taps per thread are 3.6 us of a 49.5 us frame
-    const float fake = __uint_as_float((uint32_t)(size_t)q & 0x3fffffu) * 1e-7f, fake2 = __uint_as_float((uint32_t)(size_t)below & 0x3fffffu) * 1e-7f;
-    tap[k][0] = Rgb{fake, fake2, fake}; tap[k][1] = Rgb{fake2, fake, fake2}; tap[k][2] = Rgb{fake, fake, fake2}; tap[k][3] = Rgb{fake2, fake2, fake};
+    // measurement build only (wrong colours): no loads, the addresses kept alive
+    const uint32_t fake = ((uint32_t)(size_t)q & 0x03ff03ffu) | 0x30003000u, fake2 = ((uint32_t)(size_t)below & 0x03ff03ffu) | 0x30003000u;
+    top[k] = make_uint4(fake, fake2, fake, 0u); bottom[k] = make_uint4(fake2, fake, fake2, 0u);
 #else
-    tap[k][0] = q[0]; tap[k][1] = q[1]; tap[k][2] = below[0]; tap[k][3] = below[1];
+    top[k] = *q; bottom[k] = *below;
 #endif
   }
-  pack_color_pair(weigh4_of_pair<0>(tap[0], fa.w), weigh4_of_pair<1>(tap[1], fa.w), out[0], out[1]);
-  pack_color_pair(weigh4_of_pair<0>(tap[2], fb.w), weigh4_of_pair<1>(tap[3], fb.w), out[2], out[3]);
+  pack_color_pair(weigh_pairs<0>(top[0], bottom[0], fa.w), weigh_pairs<1>(top[1], bottom[1], fa.w), out[0], out[1]);
+  pack_color_pair(weigh_pairs<0>(top[2], bottom[2], fb.w), weigh_pairs<1>(top[3], bottom[3], fb.w), out[2], out[3]);
 }
 
 // The skybox pass is cut into the same 32 x 32 pixel tiles as the rasteriser.  A tile can be shaded by
