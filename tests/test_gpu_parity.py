@@ -289,19 +289,22 @@ def test_orbit_sweep_matches_oracle(small):
     FMA contraction - put the level on the other side)."""
     cam = small.pkg.Camera()
     small.renderer.camera = cam
-    beyond, mismatched = 0, 0
+    beyond, mismatched, mismatched_sky, sky_beyond_one = 0, 0, 0, 0
     for frame in range(0, 360, 10):
         rgba, vis = small.render_gpu()
         orgba, ovis, margin = small.render_oracle_with_margins()
         assert (vis == ovis).all(), frame
         _, d = assert_frame_close(rgba, orgba, vis, ovis, f"orbit frame {frame}")
         assert (margin[d > 2] < LOD_SLACK).all(), (frame, int((d > 2).sum()))
-        beyond += int((d > 2).sum()); mismatched += int((d > 0).sum())
+        beyond += int((d > 2).sum()); mismatched += int(((d > 0) & (vis > 0)).sum())
+        mismatched_sky += int(((d > 0) & (vis == 0)).sum()); sky_beyond_one += int(((d > 1) & (vis == 0)).sum())
         for _ in range(10):
             cam.update_camera_rotation(-10.0, 0.0)
     pixels = 36 * small.width * small.height
-    print(f"orbit sweep: {beyond} of {pixels} pixels beyond 2/255, every one with a decision margin below {LOD_SLACK:g}; {mismatched} differ at all")
-    assert beyond / pixels <= 5e-6 and mismatched / pixels < 0.02, (beyond, mismatched)
+    print(f"orbit sweep: {beyond} of {pixels} pixels beyond 2/255, every one with a decision margin below {LOD_SLACK:g}; {mismatched} of the helmet's "
+          f"and {mismatched_sky} of the skybox's differ at all, {sky_beyond_one} of the skybox's by more than one step")
+    # the skybox's taps are in halves: one 8-bit step on a few per cent of its pixels, never two
+    assert beyond / pixels <= 5e-6 and mismatched / pixels < 0.02 and mismatched_sky / pixels < 0.06 and sky_beyond_one == 0, (beyond, mismatched, mismatched_sky, sky_beyond_one)
     small.renderer.camera = small.pkg.Camera()
 
 

@@ -94,6 +94,14 @@ PBR_DEV void cube_face_coords(int face, V3 d, float& sc, float& tc, float& rc) {
 // pixels.  Each element goes through exactly the operations of the one-pixel functions above.
 typedef float f2 __attribute__((ext_vector_type(2)));
 
+// x * y + z for x, y below 2^24, spelled out: from __umul24 and an addition the compiler, when it knows a factor small
+// or wants the sum as a 64-bit index, makes a v_mad_u64_u32 (or v_mad_i64_i32), which issues at a quarter of the rate.
+PBR_DEV uint32_t mad_u24(uint32_t x, uint32_t y, uint32_t z) {
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
+
 struct CubeFootPair { uint32_t o[2]; uint32_t m; f2 w[4]; };   // element k of each weight belongs to the pixel with offset o[k] (counted from level 0)
 
 // cube_foot on level 0 for two lookups at once (faces and face coordinates given per element).
@@ -114,8 +122,8 @@ PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int f
   f.w[0] = oma * omb; f.w[1] = a * omb; f.w[2] = oma * b; f.w[3] = a * b;
   const int i0 = (int)tu.x, j0 = (int)tv.x, i1 = (int)tu.y, j1 = (int)tv.y;
   // texel index with 24-bit multiply-adds (face * m + row and m are far below 2^24 for any cube the library accepts)
-  f.o[0] = __umul24(__umul24((uint32_t)face0, (uint32_t)m) + (uint32_t)j0, (uint32_t)m) + (uint32_t)i0;
-  f.o[1] = __umul24(__umul24((uint32_t)face1, (uint32_t)m) + (uint32_t)j1, (uint32_t)m) + (uint32_t)i1;
+  f.o[0] = mad_u24(mad_u24((uint32_t)face0, (uint32_t)m, (uint32_t)j0), (uint32_t)m, (uint32_t)i0);
+  f.o[1] = mad_u24(mad_u24((uint32_t)face1, (uint32_t)m, (uint32_t)j1), (uint32_t)m, (uint32_t)i1);
   f.m = (uint32_t)m;
   return f;
 }
@@ -126,13 +134,20 @@ PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int f
 // eleven significant bits: the colour moves by up to a thousandth of itself, a tenth of an 8-bit step after the gamma
 // curve, so about one pixel in ten lands on the neighbouring 8-bit value and none moves further.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+// texels . w with nothing to add to: the three-operand form of the instruction takes the zero as a constant, where the
+// builtin compiles to the accumulating two-operand form and a move that clears its accumulator first
+PBR_DEV float dot2_alone(uint32_t texels, h2 w) {
+  float r;
+  uint32_t wb; __builtin_memcpy(&wb, &w, 4);
+  asm("v_dot2_f32_f16 %0, %1, %2, 0" : "=v"(r) : "v"(texels), "v"(wb));
+  return r;
+}
 template <int E>
 PBR_DEV V3 weigh_pairs(const uint4& top, const uint4& bottom, const f2 w[4]) {
   const h2 wt = __builtin_convertvector((f2){w[0][E], w[1][E]}, h2), wb = __builtin_convertvector((f2){w[2][E], w[3][E]}, h2);
   auto halves = [](uint32_t v) { h2 r; __builtin_memcpy(&r, &v, 4); return r; };
-  return v3(__builtin_amdgcn_fdot2(halves(top.x), wt, __builtin_amdgcn_fdot2(halves(bottom.x), wb, 0.0f, false), false),
-            __builtin_amdgcn_fdot2(halves(top.y), wt, __builtin_amdgcn_fdot2(halves(bottom.y), wb, 0.0f, false), false),
-            __builtin_amdgcn_fdot2(halves(top.z), wt, __builtin_amdgcn_fdot2(halves(bottom.z), wb, 0.0f, false), false));
+  return v3(__builtin_amdgcn_fdot2(halves(top.x), wt, dot2_alone(bottom.x, wb), false), __builtin_amdgcn_fdot2(halves(top.y), wt, dot2_alone(bottom.y, wb), false),
+            __builtin_amdgcn_fdot2(halves(top.z), wt, dot2_alone(bottom.z, wb), false));
 }
 
 // pack_color for two pixels: the two multiplies of each channel run two-wide.
@@ -258,7 +273,7 @@ PBR_DEV void sky_tile(const FrameParams* __restrict__ p, const DevCubeRgb& sky, 
   if (x >= p->W || y >= p->y1) return;
   uint32_t c[4];
   sky_pixels4(p, sky, x, y, c);
-  const size_t o = (size_t)(y - p->y0) * p->W + x;
+  const uint32_t o = mad_u24((uint32_t)(y - p->y0), (uint32_t)p->W, (uint32_t)x);   // a row range has fewer than 2^32 pixels
   if (x + 3 < p->W && (o & 3) == 0) { store_colour4(rgba8 + o, c); return; }
 #pragma unroll
   for (int k = 0; k < 4; ++k) if (x + k < p->W) rgba8[o + k] = c[k];
