@@ -446,6 +446,54 @@ def test_view_without_geometry_is_all_skybox(small):
         r.camera = small.pkg.Camera()
 
 
+def test_skybox_texels_beyond_the_range_of_halves():
+    """The skybox pass samples a copy of its cube in halves (largest finite value 65504, smallest step 6e-8).  A small
+    cube written through the device pointer with texels from 1e-7 to 1e6, a NaN and an infinity, magnified twenty
+    times: within 2/255 of the oracle's f32 blend of the same texels but for a few pixels in a hundred thousand (a texel
+    beyond 65504 is clamped to it, five hundred times white, so only a pixel that gives such a texel a weight of a few
+    millionths can tell), and never more than one step off on more than a thousandth of the frame; an infinity stays
+    one, so its neighbourhood is white, and a NaN's is black, on both sides."""
+    import torch
+    s = pu.SmallScene.build(width=512, height=288, hdr_size=(256, 128), sky_size=16, pre_size=16, pre_mips=3, lut_size=32, irr_size=8)
+    try:
+        from wgpu_renderer_amd import parallel      # importable once the scene has loaded the package
+        lib, r = s.pkg._lib, s.renderer
+        rng = np.random.default_rng(7)
+        sky = np.ones((6, 16, 16, 4), np.float32)
+        sky[..., :3] = np.exp(rng.uniform(np.log(1e-7), np.log(1e3), (6, 16, 16, 3))).astype(np.float32)
+        bright = rng.random((6, 16, 16)) < 0.05
+        sky[bright, :3] = np.float32(1e6) * rng.uniform(0.5, 1.0, (int(bright.sum()), 3)).astype(np.float32)
+        sky[rng.random((6, 16, 16)) < 0.03, :3] = 0.0
+        sky[4, 3, 5, 1] = np.nan
+        sky[5, 9, 9, 0] = np.inf
+        sky[1, 12, 2, 2] = np.nan
+        ptr, total = C.c_void_p(), C.c_size_t()
+        lib.check(r._ctx, r._lib.pbr_ibl_device_ptr(r._ctx, lib.MAP_SKYBOX, C.byref(ptr), C.byref(total)))
+        assert total.value == sky.nbytes
+        view = parallel.device_bytes_tensor(ptr.value, total.value, torch.device("cuda", 0))
+        view.copy_(torch.from_numpy(sky.view(np.uint8).reshape(-1)))
+        torch.cuda.synchronize()
+        lib.check(r._ctx, r._lib.pbr_ibl_device_ptr(r._ctx, lib.MAP_SKYBOX, C.byref(ptr), C.byref(total)))   # the map was written: rebuild its copies
+        assert (r.download_map(lib.MAP_SKYBOX).view(np.uint32) == sky.view(np.uint32)).all()
+        seen_nan = seen_white = 0
+        for rotate in ((-1800.0, 0.0), (-450.0, 350.0), (900.0, -600.0)):
+            r.camera = s.pkg.Camera()
+            r.camera.update_camera_rotation(*rotate)
+            r.camera.update_camera_target(4000.0, 0.0)      # the helmet far off to the side: the frame is all skybox
+            rgba, vis = r.draw_frame(want_vis=True)
+            with s.oracle.with_maps(s.gpu_maps()):
+                orgba, ovis = s.render_oracle()
+            assert (vis == 0).all() and (ovis == 0).all()
+            d = np.abs(rgba.astype(np.int32) - orgba.astype(np.int32)).max(-1)
+            print(f"skybox of extreme texels, view {rotate}: {float((d > 0).mean()):.4f} of the pixels one step off, {int((d > 1).sum())} further, {int((d > 2).sum())} beyond 2/255")
+            assert (d > 2).mean() <= 1e-4 and (d > 1).mean() <= 1e-3
+            seen_nan += int(((orgba[..., :3] == 0).any(-1) & (rgba[..., :3] == orgba[..., :3]).all(-1)).sum())
+            seen_white += int(((orgba[..., :3] == 255).all(-1) & (rgba[..., :3] == 255).all(-1)).sum())
+        assert seen_nan > 0 and seen_white > 0
+    finally:
+        s.renderer.close()
+
+
 def test_strips_equal_full_frame(small):
     r = small.renderer
     r.camera = small.pkg.Camera()
