@@ -95,7 +95,8 @@ PBR_DEV void cube_face_coords(int face, V3 d, float& sc, float& tc, float& rc) {
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 // x * y + z for x, y below 2^24, spelled out: from __umul24 and an addition the compiler, when it knows a factor small
-// or wants the sum as a 64-bit index, makes a v_mad_u64_u32 (or v_mad_i64_i32), which issues at a quarter of the rate.
+// or wants the sum as a 64-bit index, makes a v_mad_u64_u32 (or v_mad_i64_i32) into a register pair and clears the
+// pair's upper half first; this is one instruction into one register.
 PBR_DEV uint32_t mad_u24(uint32_t x, uint32_t y, uint32_t z) {
   uint32_t r;
   asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
