@@ -439,9 +439,9 @@ def test_view_without_geometry_is_all_skybox(small):
         assert (ovis == 0).all() and (vis == 0).all() and st.covered_pixels == 0
         d = np.abs(rgba.astype(np.int32) - orgba.astype(np.int32)).max(-1)
         # the skybox is sampled from a copy of the cube in halves with weights in halves (a tenth of an 8-bit step after
-        # the gamma curve): the neighbouring 8-bit value in about one pixel of ten, never the one after it
+        # the gamma curve): the neighbouring 8-bit value in a few pixels of a hundred, never the one after it
         print(f"skybox alone: {float((d > 0).mean()):.4f} of the pixels one step off, {int((d > 1).sum())} further")
-        assert d.max() <= 2 and (d > 1).mean() <= 1e-3 and (d > 0).mean() < 0.2
+        assert d.max() <= 2 and (d > 1).mean() <= 1e-3 and (d > 0).mean() < 0.08
     finally:
         r.camera = small.pkg.Camera()
 

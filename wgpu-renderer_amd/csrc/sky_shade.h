@@ -133,7 +133,7 @@ PBR_DEV CubeFootPair cube_foot_pair(const DevCubeRgb& bordered, int face0, int f
 // are the entries at the footprint's two rows, each holding the row's two texels channel by channel, so a channel is
 // two v_dot2_f32_f16 (products and sums in f32) against the rows' weights rounded to halves.  Texels and weights carry
 // eleven significant bits: the colour moves by up to a thousandth of itself, a tenth of an 8-bit step after the gamma
-// curve, so about one pixel in ten lands on the neighbouring 8-bit value and none moves further.
+// curve, so a few pixels in a hundred land on the neighbouring 8-bit value and none moves further.
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 // texels . w with nothing to add to: the three-operand form of the instruction takes the zero as a constant, where the
 // builtin compiles to the accumulating two-operand form and a move that clears its accumulator first
