@@ -425,7 +425,7 @@ static int check_sticky(PbrContext* c) {
 
 static int refresh_bordered(PbrContext* c, PbrContextPrivate::Bordered& b, const DevCube& src, bool with_pairs = false) {
   if (!b.dirty && b.d) return PBR_OK;
-  if (!b.d || b.cube.size != src.size || b.cube.levels != src.levels) {
+  if (!b.d || (with_pairs && !b.d_pairs) || b.cube.size != src.size || b.cube.levels != src.levels) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (b.d) { (void)hipFree(b.d); b.d = nullptr; }
     if (b.d_pairs) { (void)hipFree(b.d_pairs); b.d_pairs = nullptr; b.cube.pairs = nullptr; }
