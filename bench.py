@@ -298,7 +298,10 @@ def init_distributed(args, torch, dist):
 
 
 def timed_region(torch, dist, use_dist, dev, steps, step_fn):
-    """EXACTLY `steps` steps between a barrier + synchronize on both sides; returns the max over ranks, in seconds."""
+    """EXACTLY `steps` steps between a barrier + synchronize on both sides; returns the max over ranks, in seconds.
+    A rank's clock stops when its own steps have completed (after its synchronize); the closing barrier follows, and the
+    maximum over the ranks is what a clock stopped behind the barrier would read, less the barrier's own latency (a
+    collective and a host wait, some 50-100 us, which is a tenth of a 20-step region)."""
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -306,9 +309,9 @@ def timed_region(torch, dist, use_dist, dev, steps, step_fn):
     for i in range(steps):
         step_fn(i)
     torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
     if use_dist:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
